@@ -1,0 +1,241 @@
+"""Pins the CPU oracle (oracle/) before anything trusts it.
+
+The reference stores no golden outputs (test/runtests.jl holds one differential
+test), so the oracle is pinned by restatements that are independent of it:
+exact rational known answers, a numpy fp64 restatement on the reference's own
+fixture, and the values recorded at survey time.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import GOLDEN
+
+
+def _kat_rows():
+    with open(os.path.join(GOLDEN, "kat_interaction.json")) as fh:
+        return json.load(fh)["rows"]
+
+
+def _model64(orc, row):
+    m = orc.Model64()
+    m.rc2, m.rs2, m.inv_delta2 = row["rc2"], row["rs2"], row["inv_delta2"]
+    return m
+
+
+def test_interaction_exact_rational_kats_f64(oracle):
+    """interaction() vs closed-form values in exact rational arithmetic (src/lennard_jones.jl:25-42)."""
+    for row in _kat_rows():
+        m = _model64(oracle, row)
+        ai = (row["half_sigma_i"], row["twice_sqrt_eps_i"])
+        aj = (row["half_sigma_j"], row["twice_sqrt_eps_j"])
+        E, W = oracle.interaction(row["r2"], m, ai, aj, oracle.LITERAL)
+        scale = max(abs(row["E"]), abs(row["W"]), 1e-300)
+        assert abs(E - row["E"]) <= 1e-12 * scale + 1e-15, row
+        assert abs(W - row["W"]) <= 1e-12 * scale + 1e-13, row
+        Ec, Wc = oracle.interaction(row["r2"], m, ai, aj, oracle.CUTOFF)
+        if row["beyond_cutoff"]:
+            assert (Ec, Wc) == (0.0, 0.0)          # CUTOFF drops r2 >= rc2 (Q1/Q2)
+        else:
+            assert (Ec, Wc) == (E, W)              # identical inside the cutoff
+
+
+def test_interaction_survey_values(oracle):
+    """The survey-time table of SURVEY.md 8(c) (a second, earlier restatement)."""
+    m = oracle.model(3.0, 2.5)
+    a = (0.5, 2.0)
+    table = {0.95: (1.960974656887615e+00, 5.618067529064674e+01), 1.0: (0.0, 24.0),
+             1.5: (-3.203365942785746e-01, -1.737043246569233e+00),
+             2.5: (-1.631689113600000e-02, -9.749869363200002e-02),
+             2.6: (-1.229538236539820e-02, -1.169719886315101e-01),
+             2.75: (-5.006131934194279e-03, -1.247273985325205e-01),
+             2.9: (-4.679297634217142e-04, -3.778420084297349e-02),
+             2.99: (-5.589954148723520e-07, -4.983949716412851e-04)}
+    for r, (E0, W0) in table.items():
+        E, W = oracle.interaction(r * r, m, a, a, oracle.LITERAL)
+        assert E == pytest.approx(E0, rel=1e-10, abs=1e-15)
+        assert W == pytest.approx(W0, rel=1e-10, abs=1e-12)
+    E, W = oracle.interaction(2.0 ** (1.0 / 3.0), m, a, a)         # r = 2^(1/6): minimum of LJ
+    assert E == pytest.approx(-1.0, rel=1e-14) and abs(W) < 1e-13
+    E, W = oracle.interaction(3.5 * 3.5, m, a, a, oracle.LITERAL)  # Q1: full LJ beyond rc
+    assert E == pytest.approx(-2.1747802e-03, rel=1e-6) and W == pytest.approx(-1.3041579e-02, rel=1e-6)
+    m2 = oracle.model(2.5, 2.0)
+    for r, (E0, W0) in {2.0: (-6.152343750000000e-02, -3.632812500000000e-01),
+                        2.25: (-1.688593301999643e-02, -3.570558867551361e-01),
+                        2.4: (-1.509251577777293e-03, -1.018174201003912e-01)}.items():
+        E, W = oracle.interaction(r * r, m2, a, a)
+        assert E == pytest.approx(E0, rel=1e-10) and W == pytest.approx(W0, rel=1e-10)
+
+
+def test_interaction_f32_follows_reference_precision(oracle):
+    """Float32 instantiation (the reference's precision) agrees with the exact values to fp32 rounding."""
+    for row in _kat_rows():
+        m = oracle.Model32()
+        m.rc2, m.rs2, m.inv_delta2 = row["rc2"], row["rs2"], row["inv_delta2"]
+        ai = (row["half_sigma_i"], row["twice_sqrt_eps_i"])
+        aj = (row["half_sigma_j"], row["twice_sqrt_eps_j"])
+        E, W = oracle.interaction(row["r2"], m, ai, aj, oracle.LITERAL)
+        scale = max(abs(row["E"]), abs(row["W"]))
+        # the switch window amplifies the Float32 rounding of x by ~30 g'(x): 2e-4 of the larger term
+        assert abs(E - row["E"]) <= 2e-4 * scale + 1e-7
+        assert abs(W - row["W"]) <= 2e-4 * scale + 1e-6
+
+
+def test_clamp_quirks_q1_q2(oracle):
+    """x<0 -> 0, x>1 -> 0 (g = 1 beyond rc), x == 1 -> 0.5, x == 0 -> 0 (src/lennard_jones.jl:37)."""
+    m = oracle.model(3.0, 2.5)
+    a = (0.5, 2.0)
+    lj = lambda r2: (4 * (r2 ** -6 - r2 ** -3), 24 * (2 * r2 ** -6 - r2 ** -3))
+    E, W = oracle.interaction(4.0, m, a, a)                        # r = 2 < rs: pure LJ
+    assert (E, W) == pytest.approx(lj(4.0), rel=1e-14)
+    E, W = oracle.interaction(16.0, m, a, a, oracle.LITERAL)       # r = 4 > rc: pure LJ again (Q1)
+    assert (E, W) == pytest.approx(lj(16.0), rel=1e-14)
+    E, W = oracle.interaction(9.0, m, a, a, oracle.LITERAL)        # r2 == rc2: x = 0.5 -> g = 0.5 (Q2)
+    assert E == pytest.approx(0.5 * lj(9.0)[0], rel=1e-12)
+    assert oracle.interaction(9.0, m, a, a, oracle.CUTOFF) == (0.0, 0.0)   # strict r2 < rc2
+
+
+@pytest.mark.parametrize("mode", ["literal", "cutoff"])
+def test_naive_f64_on_reference_fixture(oracle, lj_sample, golden, mode):
+    """All-pairs oracle vs the independent numpy restatement on test/data/lj_sample.xyz."""
+    g = golden["lj_sample_expected"]
+    m = oracle.model(3.0, 2.5)
+    atoms = oracle.lj_atoms(1.0, 1.0, 800)
+    f, e, w = oracle.naive(lj_sample.astype(np.float64), 10.0, m, atoms,
+                           oracle.LITERAL if mode == "literal" else oracle.CUTOFF)
+    np.testing.assert_allclose(f, g["forces_" + mode], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(e, g["energies_" + mode], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(w, g["virials_" + mode], rtol=1e-10, atol=1e-10)
+
+
+def test_reference_fixture_totals_match_survey(oracle, lj_sample):
+    """SURVEY.md 8(c) totals on lj_sample.xyz (survey-time numpy restatement)."""
+    m = oracle.model(3.0, 2.5)
+    atoms = oracle.lj_atoms(1.0, 1.0, 800)
+    x = lj_sample.astype(np.float64)
+    f, e, w = oracle.naive(x, 10.0, m, atoms, oracle.LITERAL)
+    assert e.sum() == pytest.approx(-4466.170949619774, rel=1e-12)
+    assert w.sum() == pytest.approx(-2000.6794145109884, rel=1e-12)
+    assert f[0] == pytest.approx([-10.64328702, -3.4714277, -16.41018877], rel=1e-8)
+    assert e[0] == pytest.approx(-5.592611750406278, rel=1e-12)
+    f, e, w = oracle.naive(x, 10.0, m, atoms, oracle.CUTOFF)
+    assert e.sum() == pytest.approx(-4292.184050996729, rel=1e-12)
+    assert w.sum() == pytest.approx(-957.3125855282784, rel=1e-12)
+    assert e[0] == pytest.approx(-5.369534210366058, rel=1e-12)
+    assert w[0] == pytest.approx(1.6144006748865198, rel=1e-12)
+    assert np.abs(f.sum(axis=0)).max() < 1e-9                       # Newton's third law
+
+
+def test_reference_test_bound_f32_vs_f64(oracle, lj_sample):
+    """The reference's own bound (test/runtests.jl:39-41): two implementations agree to 1e-4 in Float32."""
+    m32, m64 = oracle.model(3.0, 2.5, np.float32), oracle.model(3.0, 2.5)
+    atoms = oracle.lj_atoms(1.0, 1.0, 800)
+    f32, e32, w32 = oracle.naive(lj_sample, 10.0, m32, atoms, oracle.LITERAL)
+    f64, e64, w64 = oracle.naive(lj_sample.astype(np.float64), 10.0, m64, atoms, oracle.LITERAL)
+    assert np.abs(f32 - f64).max() < 1e-4 * max(1.0, np.abs(f64).max())
+    assert np.abs(e32 - e64).max() < 1e-4
+    assert np.abs(w32 - w64).max() < 2e-4
+
+
+def test_cell_path_equals_all_pairs_cutoff(oracle, lj_sample, golden):
+    """O(N) cell-list oracle == all-pairs CUTOFF oracle (the structure of the reference's differential test)."""
+    m = oracle.model(3.0, 2.5)
+    atoms = oracle.lj_atoms(1.0, 1.0, 800)
+    x = lj_sample.astype(np.float64)
+    f0, e0, w0 = oracle.naive(x, 10.0, m, atoms, oracle.CUTOFF)
+    for nt in (1, 3):
+        f1, e1, w1 = oracle.nonbonded_cells(x, 10.0, m, atoms, nthreads=nt)
+        np.testing.assert_allclose(f1, f0, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(e1, e0, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(w1, w0, rtol=1e-11, atol=1e-11)
+    m32 = oracle.model(3.0, 2.5, np.float32)
+    f2, e2, w2 = oracle.nonbonded_cells(lj_sample, 10.0, m32, atoms)
+    assert np.abs(f2 - f0).max() < 1e-3 and np.abs(e2 - e0).max() < 1e-4
+
+
+def test_fcc864_and_mixture_against_numpy(oracle, emdee_synthetic, golden):
+    syn = emdee_synthetic
+    g = golden["fcc864_expected"]
+    pos, L = syn.fcc_positions(6)
+    assert pos.shape == (864, 3) and L == pytest.approx(10.2599, abs=1e-4)
+    assert pos.sum() == g["pos_checksum"]                           # generator is bit-reproducible
+    m = oracle.model(2.5, 2.0)
+    atoms = oracle.lj_atoms(1.0, 1.0, 864)
+    for f, e, w in (oracle.naive(pos, L, m, atoms, oracle.CUTOFF), oracle.nonbonded_cells(pos, L, m, atoms)):
+        np.testing.assert_allclose(f, g["forces"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(e, g["energies"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(w, g["virials"], rtol=1e-10, atol=1e-10)
+    gm = golden["mix500_expected"]
+    pos, L = syn.fcc_positions(5)
+    types = syn.mixture_types(500)
+    assert (types == gm["types"]).all()
+    eps, sigma = syn.mixture_parameters(types)
+    atoms = oracle.lj_atoms(eps, sigma)
+    m = oracle.model(3.5, 3.0)
+    for f, e, w in (oracle.naive(pos, L, m, atoms, oracle.CUTOFF), oracle.nonbonded_cells(pos, L, m, atoms)):
+        np.testing.assert_allclose(f, gm["forces"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(e, gm["energies"], rtol=1e-11, atol=1e-12)
+
+
+def test_verlet_100_steps_against_numpy(oracle, emdee_synthetic, golden):
+    """BASELINE.json configs[0]: 864-atom fcc box, 100 velocity-Verlet steps, dt = 0.005."""
+    syn = emdee_synthetic
+    g = golden["fcc864_expected"]
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(864)
+    assert np.abs(vel).sum() == g["vel_checksum"]
+    m = oracle.model(2.5, 2.0)
+    atoms = oracle.lj_atoms(1.0, 1.0, 864)
+    for use_cells in (False, True):
+        out = oracle.verlet(pos, vel, L, m, atoms, 0.005, 100, use_cells=use_cells)
+        np.testing.assert_allclose(out["x"], g["x100"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out["v"], g["v100"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(out["epot"], g["epot"], rtol=1e-10)
+        np.testing.assert_allclose(out["ekin"], g["ekin"], rtol=1e-10)
+        etot = out["epot"] + out["ekin"]
+        assert abs(etot[-1] / etot[0] - 1.0) < 1e-4                 # NVE drift bound of SURVEY 8(c)
+    assert 2.0 * g["ekin"][0] / (3 * 864 - 3) == pytest.approx(1.0, rel=1e-12)   # exactly T* = 1
+
+
+def test_cells_convention(oracle):
+    """src/cells.jl:36,180-181: M = floor(ndiv L / cutoff); id = 1 + vx + M vy + M^2 vz."""
+    rng = np.random.default_rng(7)
+    pos = rng.uniform(-3.0, 13.0, size=(2000, 3))
+    M, index, pop = oracle.cells(pos, 10.0, 2.0, ndiv=2)
+    assert M == 10 and pop.sum() == 2000 and index.min() >= 1 and index.max() <= 1000
+    s = pos / 10.0
+    v = np.floor(M * (s - np.floor(s))).astype(np.int64)
+    np.testing.assert_array_equal(index, 1 + v[:, 0] + M * v[:, 1] + M * M * v[:, 2])
+    np.testing.assert_array_equal(pop, np.bincount(index - 1, minlength=M ** 3))
+    # the commented-out test_cells (test/runtests.jl:6-17): population is invariant under re-binning
+    M2, index2, pop2 = oracle.cells(pos + 10.0, 10.0, 2.0, ndiv=2)
+    np.testing.assert_array_equal(pop, pop2)
+    assert oracle.cells(pos.astype(np.float32), 10.0, 2.0)[0] == 10
+
+
+def test_neighbor_list_matches_brute_force(oracle, lj_sample):
+    x = lj_sample.astype(np.float64)
+    off, nb = oracle.neighbor_list(x, 10.0, 3.3)
+    d = x[:, None, :] / 10.0 - x[None, :, :] / 10.0
+    rv = 10.0 * (d - np.rint(d))
+    r2 = (rv * rv).sum(-1)
+    np.fill_diagonal(r2, 1e9)
+    want = r2 < 3.3 ** 2
+    assert off[-1] == want.sum()
+    for i in (0, 17, 799):
+        np.testing.assert_array_equal(nb[off[i]:off[i + 1]], np.nonzero(want[i])[0])
+    with pytest.raises(ValueError):
+        oracle.neighbor_list(x, 10.0, 5.5)
+
+
+def test_empty_and_tiny_inputs(oracle):
+    m = oracle.model(2.5, 2.0)
+    f, e, w = oracle.naive(np.zeros((0, 3)), 10.0, m, oracle.lj_atoms(1, 1, 0))
+    assert f.shape == (0, 3)
+    f, e, w = oracle.nonbonded_cells(np.zeros((1, 3)), 10.0, m, oracle.lj_atoms(1, 1, 1))
+    assert (f == 0).all() and e[0] == 0
+    x = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    f, e, w = oracle.nonbonded_cells(x, 6.0, m, oracle.lj_atoms(1, 1, 2))      # M = 2: de-duplicated stencil
+    assert f[0, 0] == pytest.approx(-24.0) and f[1, 0] == pytest.approx(24.0) and w.sum() == pytest.approx(24.0)
