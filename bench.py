@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- MD steps/s and pair-interactions/s of the nonbonded hot path on MI355X.
+
+Workload (BASELINE.json metric): Lennard-Jones fcc box, rho* = 0.8, rc = 2.5 sigma
+(switch at rc - 0.5), fp64, jittered lattice + Maxwell-Boltzmann velocities at T* = 1, dt = 0.005,
+skin 0.3 sigma, neighbour rebuild when any atom has moved skin/2.  A "step" is one velocity-Verlet
+step of the whole box (fused kick/drift pass + LJ force pass, rebuilds included).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cells n] [--precision f64|f32]
+                  [--rc 2.5] [--mixture] [--rebuild-every 0] [--no-cpu-baseline]
+
+N = 1: fcc 136^3 x 4 = 10,061,824 atoms (the 10^7-atom config the metric is quoted on) on one GPU.
+N > 1 (launched by torch.distributed.run, one rank per GPU): spatial domain decomposition with
+ghost-atom halo exchange over RCCL; weak scaling, every rank owns a 10^7-atom brick.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (lj_force_nbr) with HIP events
+recorded on its own stream inside the timed region; `cpu_baseline` times the CPU oracle on the host
+cores on a bounded sample of the same box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s measured copy ceiling
+RHO = 0.8
+
+
+def nbar(rc, rho=RHO):
+    return 4.0 / 3.0 * np.pi * rc ** 3 * rho
+
+
+def algorithmic_bytes_per_atom_step(w, rc):
+    """B_alg / atom-step = 21 w + 4 nbar(rc)."""
+    return 21.0 * w + 4.0 * nbar(rc)
+
+
+def force_kernel_bytes_per_atom(w, rc):
+    """Share of B_alg moved by one lj_force_nbr launch: read x (3w) + write f (3w) + one int32 per
+    in-cutoff neighbour of the full list."""
+    return 6.0 * w + 4.0 * nbar(rc)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cells", type=int, default=136, help="fcc cells per side per GPU (136 -> 10,061,824 atoms)")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--rc", type=float, default=2.5)
+    ap.add_argument("--skin", type=float, default=0.3)
+    ap.add_argument("--dt", type=float, default=0.005)
+    ap.add_argument("--mixture", action="store_true", help="binary LJ mixture (config 5)")
+    ap.add_argument("--rebuild-every", type=int, default=0, help="0 = displacement trigger; k = fixed cadence")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=63)
+    return ap.parse_args()
+
+
+def make_box(pkg, cells, mixture):
+    syn = pkg.synthetic
+    pos, L = syn.fcc_positions(cells)
+    N = pos.shape[0]
+    vel = syn.velocities(N)
+    if mixture:
+        eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+        atoms = pkg.lennard_jones_atoms(eps, sigma)
+    else:
+        atoms = pkg.lennard_jones_atoms(1.0, 1.0, N)
+    return pos, vel, atoms, L
+
+
+def cpu_baseline(pkg, args):
+    """Oracle (CPU restatement, OpenMP over all host cores) timed on a bounded sample: whole
+    velocity-Verlet steps of a smaller box of the same density and parameters; O(N) per step, so the
+    rate for the benchmark box is the sample rate scaled by the atom-count ratio."""
+    from oracle import oracle as orc
+    orc.build()
+    n = args.cpu_sample_cells
+    pos, vel, atoms, L = make_box(pkg, n, args.mixture)
+    model = orc.model(args.rc, args.rc - 0.5)
+    cores = orc.max_threads()
+    t0 = time.perf_counter()
+    f, e, w = orc.nonbonded_cells(pos, L, model, atoms)
+    t_force = time.perf_counter() - t0
+    nsteps = int(max(1, min(8, round(12.0 / max(t_force, 1e-3)))))
+    t0 = time.perf_counter()
+    orc.verlet(pos, vel, L, model, atoms, args.dt, nsteps)
+    dt_run = time.perf_counter() - t0
+    per_step = dt_run / (nsteps + 1)            # nsteps force passes + the initial one, integrator passes are noise
+    N_sample = pos.shape[0]
+    N_bench = 4 * args.cells ** 3
+    return dict(value=(1.0 / per_step) * N_sample / N_bench, unit="steps/s", cores=cores, kind="port",
+                sample="%d velocity-Verlet steps of fcc %d^3x4 = %d atoms (same rho*, rc, fp64 oracle, OpenMP cell list); "
+                       "per-step time scaled by %d/%d atoms" % (nsteps, n, N_sample, N_bench, N_sample),
+                sample_steps_per_sec=1.0 / per_step, sample_atoms=N_sample)
+
+
+def main():
+    args = parse_args()
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = 8 if args.precision == "f64" else 4
+    tdtype = torch.float64 if w == 8 else torch.float32
+    ndtype = np.float64 if w == 8 else np.float32
+    rc, rs = args.rc, args.rc - 0.5
+    model = pkg.LennardJonesModel(rc, rs)
+
+    if world == 1:
+        pos, vel, atoms, L = make_box(pkg, args.cells, args.mixture)
+        N_total = N_rank = pos.shape[0]
+        md = pkg.VelocityVerlet(pkg.cu(pos.astype(ndtype), dev), pkg.cu(vel.astype(ndtype), dev), L, model,
+                                pkg.cu(atoms, dev), skin=args.skin)
+        del pos, vel
+        run = lambda k: md.step_(k, args.dt, args.rebuild_every)
+        engine = md
+        parallelism = "single-gpu"
+    else:
+        from __graft_entry__ import load_package as _lp  # noqa: F401
+        domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
+                                                       skin=args.skin, mixture=args.mixture)
+        N_rank, N_total = domain.n_owned, domain.n_global
+        run = lambda k: domain.step_(k, args.dt, args.rebuild_every)
+        engine = domain.md
+        parallelism = "dd%s" % "x".join(str(g) for g in domain.grid)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(args.warmup)
+    fence()
+    builds0 = engine.nbr_stats()["builds"]
+    engine.profile_(True)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    force_ms, force_launches = engine.kernel_time("lj_force_nbr")
+    kd_ms, kd_launches = engine.kernel_time("verlet_kick_drift")
+    rb_ms, rb_launches = engine.kernel_time("rebuild")
+    stats = engine.nbr_stats()
+    pairs = engine.count_pairs()
+    if dist is not None:
+        tp = torch.tensor([pairs], dtype=torch.int64, device=dev)
+        dist.all_reduce(tp)
+        pairs = int(tp.item())
+    ep, ek, vir = engine.totals()
+
+    steps_per_sec = args.steps / elapsed
+    b_step = algorithmic_bytes_per_atom_step(w, rc) * N_total
+    b_force = force_kernel_bytes_per_atom(w, rc) * N_rank
+    force_avg_s = force_ms / max(force_launches, 1) * 1e-3
+    achieved = b_force / force_avg_s / 1e9 if force_launches else 0.0
+
+    out = {
+        "metric": "md_steps_per_sec",
+        "value": steps_per_sec,
+        "unit": "steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if w == 8 else "f32",
+        "data": "synthetic",
+        "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%d^3x4 per GPU), velocity-Verlet dt=%g, skin %g"
+                               % (rc, rs, " binary mixture" if args.mixture else "", N_total, args.cells, args.dt, args.skin),
+                   "atoms": N_total, "atoms_per_gpu": N_rank, "parallelism": parallelism,
+                   "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2"},
+        "pair_interactions_per_sec": pairs * steps_per_sec,
+        "pairs_in_cutoff": pairs,
+        "atom_steps_per_sec": N_total * steps_per_sec,
+        "roofline": {"bound": "hbm", "kernel": "lj_force_nbr", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": b_force, "avg_launch_ms": force_avg_s * 1e3,
+                     "launches": force_launches},
+        "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step * steps_per_sec / 1e9 / world,
+                          "unit": "GB/s per GPU", "frac": b_step * steps_per_sec / 1e9 / world / HBM_PEAK_GBS},
+        "kernels_ms": {"lj_force_nbr": [force_ms, force_launches], "verlet_kick_drift": [kd_ms, kd_launches],
+                       "rebuild(bin+sort+nbr_build)": [rb_ms, rb_launches]},
+        "neighbor_list": {"builds_in_timed_region": stats["builds"] - builds0, "listed": stats["listed"],
+                          "max_count": stats["max_count"], "capacity": stats["capacity"]},
+        "energy_per_atom": {"potential": ep / N_rank, "kinetic": ek / N_rank},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, args)
+        traffic = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic):
+            try:
+                with open(traffic) as fh:
+                    t = json.load(fh)
+                if t.get("atoms") == N_rank and t.get("dtype") == out["dtype"]:
+                    out["roofline"]["traffic"] = t.get("lj_force_nbr_bytes_per_launch")
+                    out["roofline"]["traffic_source"] = t.get("source")
+            except Exception:
+                pass
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+// iface.hpp -- precision-erased interfaces between the C ABI (capi.hip) and the two template
+// instantiations (impl_f32.hip, impl_f64.hip), so the translation units compile in parallel.
+#pragma once
+
+#include "common.hpp"
+
+namespace emdee {
+
+struct ICells {
+    virtual ~ICells() {}
+    virtual void update(const void *positions) = 0;
+    virtual int M() const = 0;
+    virtual void arrays(const int32_t **index, const int32_t **population, const int32_t **start,
+                        const int32_t **order) const = 0;
+};
+
+struct INbr {
+    virtual ~INbr() {}
+    virtual void compute(void *forces, void *energies, void *virials, const void *positions, double L,
+                         const emdee_lj_model &model, const emdee_lj_atom *atoms, int bitmask) = 0;
+    virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;
+    virtual void count_pairs(int64_t *pairs) = 0;
+};
+
+struct IMd {
+    virtual ~IMd() {}
+    virtual void set_state(int n_owned, int n_ghost, const void *pos, const void *vel, const emdee_lj_atom *atoms,
+                           const void *inv_mass) = 0;
+    virtual void get_state(void *pos, void *vel, void *frc, void *en, void *vir) = 0;
+    virtual void step(int nsteps, double dt, int rebuild_every) = 0;
+    virtual void kick_drift(double dt) = 0;
+    virtual void forces(int bitmask) = 0;
+    virtual void kick(double dt) = 0;
+    virtual bool needs_rebuild() = 0;
+    virtual void rebuild() = 0;
+    virtual void pack_positions(const int32_t *ids, int n, const double shift[3], void *buf) = 0;
+    virtual void unpack_ghosts(const void *buf, int first, int n) = 0;
+    virtual void energies(double out[3]) = 0;
+    virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;
+    virtual void count_pairs(int64_t *pairs) = 0;
+    virtual void profile(bool enable) = 0;
+    virtual void kernel_time(int kernel, double *total_ms, int64_t *launches) = 0;
+};
+
+template <typename real>
+struct Factory {
+    static ICells *cells(emdee_ctx *ctx, int N, double L, double cutoff, int ndiv);
+    static INbr *nbr(emdee_ctx *ctx, int N, double skin);
+    static IMd *md(emdee_ctx *ctx, const double lo[3], const double len[3], const int32_t per[3],
+                   const emdee_lj_model &model, double skin);
+    static void tiles(emdee_ctx *ctx, void *f, void *e, void *w, const void *pos, double L, int N,
+                      const emdee_lj_model &model, const emdee_lj_atom *atoms, int bitmask, int mode);
+    static void naive(emdee_ctx *ctx, void *f, void *e, void *w, const void *pos, double L, int N,
+                      const emdee_lj_model &model, const emdee_lj_atom *atoms, int mode);
+    static void interaction(emdee_ctx *ctx, int n, const void *r2, const emdee_lj_model &model, emdee_lj_atom ai,
+                            emdee_lj_atom aj, int mode, void *E, void *W);
+};
+
+}  // namespace emdee

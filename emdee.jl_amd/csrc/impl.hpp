@@ -1,0 +1,308 @@
+// impl.hpp -- the objects behind the C ABI handles, templated on the real type.
+#pragma once
+
+#include "allpairs.hpp"
+#include "iface.hpp"
+#include "nbsys.hpp"
+
+namespace emdee {
+
+// ------------------------------------------------------------------------------------ Cells
+// Cells(r, L, cutoff; ndiv) / update_cells! -- src/cells.jl:176-222.  head/next linked lists become
+// start/order arrays (counting sort); index and population keep the reference's meaning.
+template <typename real>
+struct CellsImpl : ICells {
+    emdee_ctx *ctx;
+    int N, Mdim;
+    GridP<real> grid{};
+    size_t ncell;
+    DevBuf<int> index, population, start, fill, tmp, order;
+    Scanner scanner;
+
+    CellsImpl(emdee_ctx *c, int n, double L, double cutoff, int ndiv) : ctx(c), N(n) {
+        EMDEE_REQUIRE(n >= 0 && L > 0 && cutoff > 0 && ndiv >= 1, EMDEE_ERR_INVALID, "Cells: need N >= 0, L > 0, cutoff > 0, ndiv >= 1");
+        Mdim = std::max(1, (int)std::floor((double)ndiv * L / cutoff));   // src/cells.jl:36
+        EMDEE_REQUIRE(Mdim <= 1290, EMDEE_ERR_INVALID, "Cells: M = %d cells per dimension overflows int32 ids", Mdim);
+        for (int d = 0; d < 3; d++) {
+            grid.lo[d] = 0; grid.len[d] = (real)L; grid.plen[d] = (real)L; grid.pinv[d] = (real)(1.0 / L);
+            grid.per[d] = 1; grid.M[d] = Mdim;
+        }
+        grid.nd = ndiv;
+        grid.one_based = 1;   // src/cells.jl:85,181
+        ncell = (size_t)Mdim * Mdim * Mdim;
+        index.ensure(n + 1); tmp.ensure(n + 1); order.ensure(n + 1);
+        population.ensure(ncell + 2); start.ensure(ncell + 2); fill.ensure(ncell + 2);
+    }
+
+    void update(const void *positions) override {
+        EMDEE_REQUIRE(positions || N == 0, EMDEE_ERR_INVALID, "Cells: positions is NULL");
+        use_device(ctx);
+        hipStream_t s = ctx->stream;
+        EMDEE_HIP_CHECK(hipMemsetAsync(population.ptr, 0, (ncell + 1) * sizeof(int), s));
+        EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, ncell * sizeof(int), s));
+        if (N > 0)
+            hipLaunchKernelGGL((k_cell_assign<real, UserPos<real>>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N,
+                               UserPos<real>{(const real *)positions}, grid, index.ptr, population.ptr);
+        EMDEE_HIP_CHECK(hipMemcpyAsync(start.ptr, population.ptr, (ncell + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+        scanner.run(start.ptr, ncell + 1, s);
+        if (N > 0) {
+            hipLaunchKernelGGL(k_cell_scatter, dim3(blocks_for(N, 256)), dim3(256), 0, s, N, index.ptr, 1, start.ptr,
+                               fill.ptr, tmp.ptr);
+            hipLaunchKernelGGL(k_cell_rankfix, dim3(blocks_for(N, 256)), dim3(256), 0, s, N, index.ptr, 1, start.ptr,
+                               tmp.ptr, (const int *)nullptr, order.ptr);
+        }
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    int M() const override { return Mdim; }
+    void arrays(const int32_t **i, const int32_t **p, const int32_t **s, const int32_t **o) const override {
+        if (i) *i = index.ptr;
+        if (p) *p = population.ptr;
+        if (s) *s = start.ptr;
+        if (o) *o = order.ptr;
+    }
+};
+
+// ------------------------------------------------------------------------------------ neighbour handle
+template <typename real>
+struct NbrImpl : INbr {
+    NbSystem<real> sys;
+    int N;
+    double L_built = -1.0;
+
+    NbrImpl(emdee_ctx *c, int n, double skin) : N(n) {
+        EMDEE_REQUIRE(n >= 0 && skin >= 0, EMDEE_ERR_INVALID, "nbr: need N >= 0 and skin >= 0");
+        sys.ctx = c;
+        sys.skin = skin;
+    }
+
+    void compute(void *forces, void *energies, void *virials, const void *positions, double L, const emdee_lj_model &model,
+                 const emdee_lj_atom *atoms, int bitmask) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of FORCES|ENERGIES|VIRIALS");
+        EMDEE_REQUIRE(!(bitmask & EMDEE_FORCES) || forces || N == 0, EMDEE_ERR_INVALID, "forces selected but NULL");
+        EMDEE_REQUIRE(!(bitmask & EMDEE_ENERGIES) || energies || N == 0, EMDEE_ERR_INVALID, "energies selected but NULL");
+        EMDEE_REQUIRE(!(bitmask & EMDEE_VIRIALS) || virials || N == 0, EMDEE_ERR_INVALID, "virials selected but NULL");
+        EMDEE_REQUIRE(L > 0, EMDEE_ERR_INVALID, "L must be positive");
+        if (N == 0 || bitmask == 0) return;
+        EMDEE_REQUIRE(positions && atoms, EMDEE_ERR_INVALID, "positions/atoms are NULL");
+        const real *pos = (const real *)positions;
+        const double lo[3] = {0, 0, 0}, len[3] = {L, L, L};
+        const int per[3] = {1, 1, 1};   // cubic periodic box, the reference's only geometry (Q9)
+        sys.set_box(lo, len, per);
+        sys.set_model(model, sys.skin);
+        bool rebuild = !sys.has_list || sys.n_total != N;
+        if (!rebuild) rebuild = sys.user_positions_moved(pos);
+        if (rebuild) sys.load_user(N, 0, pos, nullptr, atoms, nullptr);
+        else sys.refresh_user(pos, atoms);
+        sys.compute_forces(bitmask);
+        sys.unsort(nullptr, nullptr, (bitmask & EMDEE_FORCES) ? (real *)forces : nullptr,
+                   (bitmask & EMDEE_ENERGIES) ? (real *)energies : nullptr,
+                   (bitmask & EMDEE_VIRIALS) ? (real *)virials : nullptr);
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) override {
+        use_device(sys.ctx);
+        sys.list_stats(false, listed, max_count, nullptr);
+        if (builds) *builds = sys.builds;
+        if (capacity) *capacity = sys.stride;
+    }
+    void count_pairs(int64_t *pairs) override {
+        use_device(sys.ctx);
+        sys.list_stats(true, nullptr, nullptr, pairs);
+    }
+};
+
+// ------------------------------------------------------------------------------------ velocity-Verlet
+template <typename real>
+struct MdImpl : IMd {
+    NbSystem<real> sys;
+    int n_ghost = 0;
+    int since_build = 0;
+    int current_mask = 0;   // which of f/e/w match the current positions
+
+    MdImpl(emdee_ctx *c, const double lo[3], const double len[3], const int32_t per[3], const emdee_lj_model &model,
+           double skin) {
+        sys.ctx = c;
+        int p[3] = {per[0], per[1], per[2]};
+        sys.set_box(lo, len, p);
+        sys.set_model(model, skin);
+        sys.with_vel = true;
+    }
+
+    void set_state(int n_owned, int ng, const void *pos, const void *vel, const emdee_lj_atom *atoms,
+                   const void *inv_mass) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(vel || n_owned == 0, EMDEE_ERR_INVALID, "velocities are NULL");
+        n_ghost = ng;
+        sys.load_user(n_owned, ng, (const real *)pos, (const real *)vel, atoms, (const real *)inv_mass);
+        since_build = 0;
+        sys.compute_forces(EMDEE_FORCES);
+        current_mask = EMDEE_FORCES;
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void get_state(void *pos, void *vel, void *frc, void *en, void *vir) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
+        if ((en || vir) && (current_mask & 6) != 6) forces(7);
+        sys.unsort((real *)pos, (real *)vel, (real *)frc, (real *)en, (real *)vir);
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void step(int nsteps, double dt, int rebuild_every) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
+        EMDEE_REQUIRE(n_ghost == 0, EMDEE_ERR_STATE, "md_step needs n_ghost == 0; decomposed runs drive kick_drift/forces/kick");
+        EMDEE_REQUIRE(nsteps >= 0 && dt >= 0, EMDEE_ERR_INVALID, "md_step: negative nsteps or dt");
+        if (nsteps == 0) return;
+        if (!(current_mask & EMDEE_FORCES)) forces(EMDEE_FORCES);
+        for (int s = 0; s < nsteps; s++) {
+            // closing half kick of step s-1 fused with the opening half kick of step s: one pass
+            sys.kick_drift(s == 0 ? 0.5 * dt : dt, dt);
+            since_build++;
+            bool rb = rebuild_every > 0 ? since_build >= rebuild_every : sys.read_rebuild_flag();
+            if (rb) { sys.resort(); since_build = 0; }
+            sys.compute_forces(EMDEE_FORCES);
+        }
+        sys.kick(0.5 * dt);
+        current_mask = EMDEE_FORCES;
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void kick_drift(double dt) override {
+        use_device(sys.ctx);
+        sys.kick_drift(0.5 * dt, dt);
+        since_build++;
+        current_mask = 0;
+    }
+    void forces(int bitmask) override {
+        use_device(sys.ctx);
+        sys.compute_forces(bitmask);
+        current_mask = bitmask;
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void kick(double dt) override {
+        use_device(sys.ctx);
+        sys.kick(0.5 * dt);
+    }
+    bool needs_rebuild() override {
+        use_device(sys.ctx);
+        return sys.read_rebuild_flag();
+    }
+    void rebuild() override {
+        use_device(sys.ctx);
+        sys.resort();
+        since_build = 0;
+        current_mask = 0;
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+    void pack_positions(const int32_t *ids, int n, const double shift[3], void *buf) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
+        if (n <= 0) return;
+        hipLaunchKernelGGL((k_pack_positions<real>), dim3(blocks_for(n, 256)), dim3(256), 0, sys.stream(), n, ids,
+                           sys.inv_perm.ptr, sys.rec.ptr, (real)shift[0], (real)shift[1], (real)shift[2], (real *)buf);
+    }
+    void unpack_ghosts(const void *buf, int first, int n) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
+        EMDEE_REQUIRE(first >= 0 && n >= 0 && first + n <= n_ghost, EMDEE_ERR_INVALID, "unpack_ghosts: range outside the ghosts");
+        if (n == 0) return;
+        hipLaunchKernelGGL((k_unpack_ghosts<real>), dim3(blocks_for(n, 256)), dim3(256), 0, sys.stream(), n,
+                           sys.n_owned + first, sys.inv_perm.ptr, (const real *)buf, sys.rec.ptr);
+        current_mask = 0;
+    }
+    void energies(double out[3]) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
+        if ((current_mask & 7) != 7) forces(7);
+        sys.energy_sums(0.0, out);
+    }
+    void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) override {
+        use_device(sys.ctx);
+        sys.list_stats(false, listed, max_count, nullptr);
+        if (builds) *builds = sys.builds;
+        if (capacity) *capacity = sys.stride;
+    }
+    void count_pairs(int64_t *pairs) override {
+        use_device(sys.ctx);
+        sys.list_stats(true, nullptr, nullptr, pairs);
+    }
+    void profile(bool enable) override {
+        sys.profiling = enable;
+        for (auto &t : sys.timers) t.reset();
+    }
+    void kernel_time(int kernel, double *total_ms, int64_t *launches) override {
+        EMDEE_REQUIRE(kernel >= 0 && kernel < T_COUNT, EMDEE_ERR_INVALID, "kernel id out of range");
+        use_device(sys.ctx);
+        sys.timers[kernel].collect();
+        if (total_ms) *total_ms = sys.timers[kernel].total_ms;
+        if (launches) *launches = sys.timers[kernel].launches;
+    }
+};
+
+// ------------------------------------------------------------------------------------ factories
+template <typename real>
+ICells *Factory<real>::cells(emdee_ctx *ctx, int N, double L, double cutoff, int ndiv) {
+    return new CellsImpl<real>(ctx, N, L, cutoff, ndiv);
+}
+template <typename real>
+INbr *Factory<real>::nbr(emdee_ctx *ctx, int N, double skin) {
+    return new NbrImpl<real>(ctx, N, skin);
+}
+template <typename real>
+IMd *Factory<real>::md(emdee_ctx *ctx, const double lo[3], const double len[3], const int32_t per[3],
+                       const emdee_lj_model &model, double skin) {
+    return new MdImpl<real>(ctx, lo, len, per, model, skin);
+}
+
+template <typename real>
+void Factory<real>::tiles(emdee_ctx *ctx, void *f, void *e, void *w, const void *pos, double L, int N,
+                          const emdee_lj_model &model, const emdee_lj_atom *atoms, int bitmask, int mode) {
+    use_device(ctx);
+    EMDEE_REQUIRE(N >= 0 && L > 0, EMDEE_ERR_INVALID, "tiles: need N >= 0 and L > 0");
+    EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of FORCES|ENERGIES|VIRIALS");
+    EMDEE_REQUIRE(mode == EMDEE_LITERAL || mode == EMDEE_CUTOFF, EMDEE_ERR_INVALID, "mode must be LITERAL or CUTOFF");
+    if (N == 0 || bitmask == 0) return;
+    EMDEE_REQUIRE(pos && atoms, EMDEE_ERR_INVALID, "positions/atoms are NULL");
+    EMDEE_REQUIRE((!(bitmask & 1) || f) && (!(bitmask & 2) || e) && (!(bitmask & 4) || w), EMDEE_ERR_INVALID,
+                  "a selected output is NULL");
+    LJModel<real> m = make_model<real>(model);
+    const int nt = (N + TILE - 1) / TILE;
+    if (mode == EMDEE_LITERAL)
+        hipLaunchKernelGGL((k_tiles<real, EMDEE_LITERAL>), dim3(nt), dim3(TILE_BLOCK), 0, ctx->stream, N, (const real *)pos,
+                           (real)L, atoms, m, bitmask, (real *)f, (real *)e, (real *)w);
+    else
+        hipLaunchKernelGGL((k_tiles<real, EMDEE_CUTOFF>), dim3(nt), dim3(TILE_BLOCK), 0, ctx->stream, N, (const real *)pos,
+                           (real)L, atoms, m, bitmask, (real *)f, (real *)e, (real *)w);
+    EMDEE_HIP_CHECK(hipGetLastError());
+}
+
+template <typename real>
+void Factory<real>::naive(emdee_ctx *ctx, void *f, void *e, void *w, const void *pos, double L, int N,
+                          const emdee_lj_model &model, const emdee_lj_atom *atoms, int mode) {
+    use_device(ctx);
+    EMDEE_REQUIRE(N >= 0 && L > 0, EMDEE_ERR_INVALID, "naive: need N >= 0 and L > 0");
+    EMDEE_REQUIRE(mode == EMDEE_LITERAL || mode == EMDEE_CUTOFF, EMDEE_ERR_INVALID, "mode must be LITERAL or CUTOFF");
+    if (N == 0) return;
+    EMDEE_REQUIRE(pos && atoms && f && e && w, EMDEE_ERR_INVALID, "naive: NULL array");
+    LJModel<real> m = make_model<real>(model);
+    if (mode == EMDEE_LITERAL)
+        hipLaunchKernelGGL((k_naive<real, EMDEE_LITERAL>), dim3(blocks_for(N, 64)), dim3(64), 0, ctx->stream, N,
+                           (const real *)pos, (real)L, atoms, m, (real *)f, (real *)e, (real *)w);
+    else
+        hipLaunchKernelGGL((k_naive<real, EMDEE_CUTOFF>), dim3(blocks_for(N, 64)), dim3(64), 0, ctx->stream, N,
+                           (const real *)pos, (real)L, atoms, m, (real *)f, (real *)e, (real *)w);
+    EMDEE_HIP_CHECK(hipGetLastError());
+}
+
+template <typename real>
+void Factory<real>::interaction(emdee_ctx *ctx, int n, const void *r2, const emdee_lj_model &model, emdee_lj_atom ai,
+                                emdee_lj_atom aj, int mode, void *E, void *W) {
+    use_device(ctx);
+    EMDEE_REQUIRE(n >= 0, EMDEE_ERR_INVALID, "interaction: negative n");
+    if (n == 0) return;
+    EMDEE_REQUIRE(r2 && E && W, EMDEE_ERR_INVALID, "interaction: NULL array");
+    hipLaunchKernelGGL((k_interaction<real>), dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, n, (const real *)r2,
+                       make_model<real>(model), ai, aj, mode, (real *)E, (real *)W);
+    EMDEE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace emdee

@@ -1,0 +1,6 @@
+// impl_f64.hip -- fp64 instantiation (north-star precision) of every kernel and handle object.
+#include "impl.hpp"
+
+namespace emdee {
+template struct Factory<double>;
+}

@@ -1,0 +1,647 @@
+// kernels.hpp -- device kernels of the O(N) nonbonded path, templated on the real type.
+//
+// Data layout in HBM (cell order = atoms sorted by cell id, ascending caller id inside a cell):
+//   rec[p]      one aligned record per atom: fp64 {x,y,z, half_sigma, twice_sqrt_eps} = 32 B
+//               (a neighbour gather is exactly one record: position AND LJAtom parameters);
+//               fp32 {x,y,z, half_sigma} = 16 B plus te[p] (4 B)
+//   vel/frc     structure-of-arrays, 3 planes of `pitch` reals: every streaming pass is a
+//               unit-stride 4/8-B-per-lane access
+//   nbr         row-major ELL: row p holds the neighbours of atom p at nbr[p*stride .. +cnt[p])
+//               so a wavefront reads its atom's indices as 256-B coalesced segments
+//   perm/inv    cell-order slot -> caller id and back
+//
+// Reference lines restated here: cell id convention src/cells.jl:82-85,180-181; minimum image
+// src/nonbonded.jl:40; f_ij = W/r2 * r_ij and the half split of E and W src/nonbonded.jl:136-145;
+// the pair function is lj_pair.hpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "lj_pair.hpp"
+#include "wave_ops.hpp"
+
+namespace emdee {
+
+// ------------------------------------------------------------------------------------ records
+template <typename real>
+struct Rec;
+template <>
+struct alignas(32) Rec<double> {
+    double x, y, z;
+    float hs, te;
+};
+template <>
+struct alignas(16) Rec<float> {
+    float x, y, z, hs;
+};
+
+// read-only view of the cell-ordered atoms
+template <typename real>
+struct AtomView {
+    const Rec<real> *rec;
+    const float *te;   // fp32 only (fp64 keeps te inside the record)
+};
+
+__device__ __forceinline__ void load_atom(const AtomView<double> &a, int p, double &x, double &y, double &z, double &hs,
+                                          double &te) {
+    Rec<double> r = a.rec[p];   // 2 x global_load_dwordx4
+    x = r.x; y = r.y; z = r.z; hs = (double)r.hs; te = (double)r.te;
+}
+__device__ __forceinline__ void load_atom(const AtomView<float> &a, int p, float &x, float &y, float &z, float &hs,
+                                          float &te) {
+    Rec<float> r = a.rec[p];    // 1 x global_load_dwordx4
+    x = r.x; y = r.y; z = r.z; hs = r.hs; te = a.te[p];
+}
+
+// ------------------------------------------------------------------------------------ grid
+template <typename real>
+struct GridP {
+    real lo[3], len[3];      // box
+    real plen[3], pinv[3];   // minimum image d -= plen * rint(d * pinv); both 0 on non-periodic dims
+    int per[3];
+    int M[3];                // cells per dimension
+    int nd;                  // stencil half-width in cells (cell side >= rlist / nd)
+    int one_based;           // Cells API: ids are 1-based (src/cells.jl:181)
+};
+
+// 0-based voxel of coordinate p along dimension d: floor(M (s - floor s)), s = (p - lo)/len.
+// True division, not a reciprocal multiply: the Cells API must agree bit-for-bit with the
+// reference arithmetic s = r / L (src/cells.jl:79-84,180).
+template <typename real>
+__device__ __forceinline__ int voxel(real p, real lo, real len, int M, int periodic) {
+    real s = (p - lo) / len;
+    real t = periodic ? s - floor(s) : s;
+    int v = (int)floor((real)M * t);
+    return min(max(v, 0), M - 1);
+}
+
+template <typename real>
+__device__ __forceinline__ int cell_id(const GridP<real> &g, real x, real y, real z) {
+    int vx = voxel(x, g.lo[0], g.len[0], g.M[0], g.per[0]);
+    int vy = voxel(y, g.lo[1], g.len[1], g.M[1], g.per[1]);
+    int vz = voxel(z, g.lo[2], g.len[2], g.M[2], g.per[2]);
+    return vx + g.M[0] * (vy + g.M[1] * vz);
+}
+
+template <typename real>
+__device__ __forceinline__ real min_image(real d, real plen, real pinv) {
+    return d - plen * rint(d * pinv);   // v_rndne: ties-to-even like Julia round (Q8)
+}
+
+// position sources: caller order (3xN interleaved) or cell-ordered records
+template <typename real>
+struct UserPos {
+    const real *p;
+    __device__ __forceinline__ void get(int i, real &x, real &y, real &z) const {
+        x = p[3 * (size_t)i]; y = p[3 * (size_t)i + 1]; z = p[3 * (size_t)i + 2];
+    }
+};
+template <typename real>
+struct RecPos {
+    const Rec<real> *r;
+    __device__ __forceinline__ void get(int i, real &x, real &y, real &z) const {
+        Rec<real> q = r[i];
+        x = q.x; y = q.y; z = q.z;
+    }
+};
+
+// ------------------------------------------------------------------------------------ binning
+// Radix-count pass of the counting sort: one digit = the cell id.
+template <typename real, class Src>
+__global__ void k_cell_assign(int n, Src src, GridP<real> g, int *__restrict__ cell_of, int *__restrict__ count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    real x, y, z;
+    src.get(i, x, y, z);
+    int c = cell_id(g, x, y, z);
+    cell_of[i] = c + g.one_based;
+    atomicAdd(&count[c], 1);
+}
+
+// Scatter ids into their cell's range (arrival order inside a cell is arbitrary here)...
+static __global__ void k_cell_scatter(int n, const int *__restrict__ cell_of, int one_based, const int *__restrict__ start,
+                               int *__restrict__ fill, int *__restrict__ tmp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = cell_of[i] - one_based;
+    int slot = start[c] + atomicAdd(&fill[c], 1);
+    tmp[slot] = i;
+}
+
+// ...then make it deterministic: inside each cell order by key (caller id), by counting smaller
+// keys among the cell-mates (cells hold O(10) atoms).  order[q] = source index of slot q.
+static __global__ void k_cell_rankfix(int n, const int *__restrict__ cell_of, int one_based, const int *__restrict__ start,
+                               const int *__restrict__ tmp, const int *__restrict__ key, int *__restrict__ order) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int i = tmp[q];
+    int c = cell_of[i] - one_based;
+    int s = start[c], e = start[c + 1];
+    int ki = key ? key[i] : i;
+    int rank = 0;
+    for (int r = s; r < e; r++) {
+        int j = tmp[r];
+        int kj = key ? key[j] : j;
+        rank += (kj < ki) ? 1 : 0;
+    }
+    order[s + rank] = i;
+}
+
+// ------------------------------------------------------------------------------------ scan
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// exclusive scan of one tile per block, tile totals to sums[]
+static __global__ void k_scan_tiles(const int *__restrict__ in, int *__restrict__ out, size_t n, int *__restrict__ sums) {
+    __shared__ int wave_tot[SCAN_THREADS / WAVE];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        tsum += v[k];
+    }
+    // inclusive scan of tsum over the wave via DPP-free shuffles (ints, cheap), then across waves
+    int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int inc = tsum;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == WAVE - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / WAVE; w++) {
+        if (w < wv) wave_off += wave_tot[w];
+        total += wave_tot[w];
+    }
+    int run = wave_off + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0 && sums) sums[blockIdx.x] = total;
+}
+
+static __global__ void k_scan_add(int *__restrict__ out, size_t n, const int *__restrict__ offs) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += offs[i / SCAN_TILE];
+}
+
+// ------------------------------------------------------------------------------------ gathers
+// Build the cell-ordered state from caller-order arrays.  order[p] = caller id of slot p.
+template <typename real>
+__global__ void k_gather_user(int n, int n_owned, size_t pitch, const int *__restrict__ order,
+                              const int *__restrict__ cell_of, const real *__restrict__ pos,
+                              const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ vel,
+                              const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
+                              real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
+                              int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted);
+
+// Re-sort an already cell-ordered state (MD rebuild). order[p] = OLD slot of new slot p.
+template <typename real>
+__global__ void k_gather_sorted(int n, size_t pitch, const int *__restrict__ order, const int *__restrict__ cell_of,
+                                const Rec<real> *__restrict__ rec_in, const float *__restrict__ te_in,
+                                const real *__restrict__ v_in, const real *__restrict__ im_in,
+                                const int *__restrict__ perm_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
+                                real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
+                                int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted);
+
+template <typename real>
+__device__ __forceinline__ void store_rec(Rec<real> *rec, float *te, int p, real x, real y, real z, float hs, float tev);
+template <>
+__device__ __forceinline__ void store_rec<double>(Rec<double> *rec, float *, int p, double x, double y, double z,
+                                                  float hs, float tev) {
+    Rec<double> r;
+    r.x = x; r.y = y; r.z = z; r.hs = hs; r.te = tev;
+    rec[p] = r;
+}
+template <>
+__device__ __forceinline__ void store_rec<float>(Rec<float> *rec, float *te, int p, float x, float y, float z, float hs,
+                                                 float tev) {
+    Rec<float> r;
+    r.x = x; r.y = y; r.z = z; r.hs = hs;
+    rec[p] = r;
+    te[p] = tev;
+}
+__device__ __forceinline__ void rec_params(const Rec<double> *rec, const float *, int p, float &hs, float &tev) {
+    hs = rec[p].hs; tev = rec[p].te;
+}
+__device__ __forceinline__ void rec_params(const Rec<float> *rec, const float *te, int p, float &hs, float &tev) {
+    hs = rec[p].hs; tev = te[p];
+}
+
+template <typename real>
+__global__ void k_gather_user(int n, int n_owned, size_t pitch, const int *__restrict__ order,
+                              const int *__restrict__ cell_of, const real *__restrict__ pos,
+                              const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ vel,
+                              const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
+                              real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
+                              int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int i = order[p];
+    real x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    emdee_lj_atom a = atoms[i];
+    store_rec<real>(rec, te, p, x, y, z, a.half_sigma, a.twice_sqrt_eps);
+    xb[p] = x; xb[pitch + p] = y; xb[2 * pitch + p] = z;
+    bool owned = i < n_owned;
+    if (v_out) {
+        for (int d = 0; d < 3; d++) v_out[d * pitch + p] = (owned && vel) ? vel[3 * (size_t)i + d] : (real)0;
+    }
+    if (im_out) im_out[p] = (owned && inv_mass) ? inv_mass[i] : (real)1;
+    perm[p] = i;
+    inv_perm[i] = p;
+    cell_sorted[p] = cell_of[i];
+}
+
+template <typename real>
+__global__ void k_gather_sorted(int n, size_t pitch, const int *__restrict__ order, const int *__restrict__ cell_of,
+                                const Rec<real> *__restrict__ rec_in, const float *__restrict__ te_in,
+                                const real *__restrict__ v_in, const real *__restrict__ im_in,
+                                const int *__restrict__ perm_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
+                                real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
+                                int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int o = order[p];
+    Rec<real> r = rec_in[o];
+    float hs, tev;
+    rec_params(rec_in, te_in, o, hs, tev);
+    store_rec<real>(rec, te, p, r.x, r.y, r.z, hs, tev);
+    xb[p] = r.x; xb[pitch + p] = r.y; xb[2 * pitch + p] = r.z;
+    if (v_out) {
+        for (int d = 0; d < 3; d++) v_out[d * pitch + p] = v_in[d * pitch + o];
+    }
+    if (im_out) im_out[p] = im_in[o];
+    int i = perm_in[o];
+    perm[p] = i;
+    inv_perm[i] = p;
+    cell_sorted[p] = cell_of[o];
+}
+
+// Operator path: same list, new caller positions -> refresh the records in place.
+template <typename real>
+__global__ void k_refresh_positions(int n, const int *__restrict__ perm, const real *__restrict__ pos,
+                                    const emdee_lj_atom *__restrict__ atoms, Rec<real> *__restrict__ rec,
+                                    float *__restrict__ te) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int i = perm[p];
+    emdee_lj_atom a = atoms[i];
+    store_rec<real>(rec, te, p, pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], a.half_sigma,
+                    a.twice_sqrt_eps);
+}
+
+// Operator path: has any atom moved more than sqrt(thr2) (minimum image) since the build?
+template <typename real>
+__global__ void k_check_displacement(int n, const int *__restrict__ inv_perm, const real *__restrict__ pos,
+                                     const real *__restrict__ xb, size_t pitch, GridP<real> g, real thr2,
+                                     int *__restrict__ flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = inv_perm[i];
+    real dx = min_image(pos[3 * (size_t)i] - xb[p], g.plen[0], g.pinv[0]);
+    real dy = min_image(pos[3 * (size_t)i + 1] - xb[pitch + p], g.plen[1], g.pinv[1]);
+    real dz = min_image(pos[3 * (size_t)i + 2] - xb[2 * pitch + p], g.plen[2], g.pinv[2]);
+    if (dx * dx + dy * dy + dz * dz > thr2) *flag = 1;
+}
+
+// ------------------------------------------------------------------------------------ neighbour build
+// One wavefront per atom (cell order).  The stencil is walked as rows of cells along x: in cell
+// order a row segment is ONE contiguous slot range, so the 64 lanes read 64 consecutive records
+// (coalesced), test the minimum-image distance, and compact the survivors with ballot + mbcnt.
+constexpr int NBR_BLOCK = 256;
+
+template <typename real>
+__global__ __launch_bounds__(NBR_BLOCK) void k_nbr_build(int n, int n_owned, AtomView<real> atoms,
+                                                          const int *__restrict__ perm,
+                                                          const int *__restrict__ cell_sorted,
+                                                          const int *__restrict__ start, GridP<real> g, real rlist2,
+                                                          int *__restrict__ nbr, int stride, int *__restrict__ cnt,
+                                                          int *__restrict__ overflow) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (NBR_BLOCK / WAVE) + threadIdx.x / WAVE);
+    if (p >= n) return;
+    if (perm[p] >= n_owned) {   // ghosts act on owned atoms but own no row
+        if (lane == 0) cnt[p] = 0;
+        return;
+    }
+    real xi, yi, zi, hs_unused, te_unused;
+    load_atom(atoms, p, xi, yi, zi, hs_unused, te_unused);
+    const int c = cell_sorted[p];
+    const int Mx = g.M[0], My = g.M[1], Mz = g.M[2], nd = g.nd;
+    const int cx = c % Mx, cy = (c / Mx) % My, cz = c / (Mx * My);
+    int *row = nbr + (size_t)p * stride;
+    int count = 0;
+
+    const int span = 2 * nd + 1;
+    const int nz = g.per[2] ? min(span, Mz) : span;
+    const int ny = g.per[1] ? min(span, My) : span;
+    for (int kz = 0; kz < nz; kz++) {
+        int zz = cz - nd + kz;
+        if (g.per[2]) zz = ((zz % Mz) + Mz) % Mz;
+        else if (zz < 0 || zz >= Mz) continue;
+        for (int ky = 0; ky < ny; ky++) {
+            int yy = cy - nd + ky;
+            if (g.per[1]) yy = ((yy % My) + My) % My;
+            else if (yy < 0 || yy >= My) continue;
+            const int base = (zz * My + yy) * Mx;
+            // x range of this row as one or two contiguous cell segments
+            int xa0, xb0, xa1 = 0, xb1 = -1;
+            int xa = cx - nd, xb = cx + nd;
+            if (g.per[0]) {
+                if (Mx <= span) { xa0 = 0; xb0 = Mx - 1; }
+                else if (xa < 0) { xa0 = xa + Mx; xb0 = Mx - 1; xa1 = 0; xb1 = xb; }
+                else if (xb >= Mx) { xa0 = xa; xb0 = Mx - 1; xa1 = 0; xb1 = xb - Mx; }
+                else { xa0 = xa; xb0 = xb; }
+            } else {
+                xa0 = max(xa, 0); xb0 = min(xb, Mx - 1);
+            }
+            for (int seg = 0; seg < 2; seg++) {
+                const int a = seg ? xa1 : xa0, b = seg ? xb1 : xb0;
+                if (b < a) continue;
+                const int s = start[base + a], e = start[base + b + 1];
+                for (int q0 = s; q0 < e; q0 += WAVE) {
+                    const int q = q0 + lane;
+                    bool pass = false;
+                    if (q < e && q != p) {
+                        real xj, yj, zj, hs_j, te_j;
+                        load_atom(atoms, q, xj, yj, zj, hs_j, te_j);
+                        real dx = min_image(xi - xj, g.plen[0], g.pinv[0]);
+                        real dy = min_image(yi - yj, g.plen[1], g.pinv[1]);
+                        real dz = min_image(zi - zj, g.plen[2], g.pinv[2]);
+                        pass = dx * dx + dy * dy + dz * dz < rlist2;
+                    }
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) {
+                        const int k = count + prefix_popc(mask);
+                        if (k < stride) row[k] = q;
+                    }
+                    count += __popcll(mask);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        cnt[p] = min(count, stride);
+        if (count > stride) atomicMax(overflow, count);   // rare: host grows the stride and rebuilds
+    }
+}
+
+// ------------------------------------------------------------------------------------ force kernel
+// lj_force_nbr: one wavefront per atom.  Each block owns FORCE_ATOMS consecutive atoms (cell
+// order), each of its 4 waves walks FORCE_ATOMS/4 of them: the 64 lanes read 64 neighbour
+// indices per 256-B segment, gather one record each, evaluate the pair function, and the
+// per-lane partial sums are combined with DPP row shifts/broadcasts.  Results are staged in
+// LDS and stored once per block as unit-stride segments of the SoA force planes: no atomics,
+// no pre-zeroing (the reference zero-fills and atomically accumulates, src/nonbonded.jl:88-104,
+// 112-114).  Block ids are remapped so that each XCD (private L2) owns one contiguous span of
+// atoms: neighbouring atoms gather the same records.
+constexpr int FORCE_BLOCK = 256;
+constexpr int FORCE_ATOMS = 64;
+constexpr int NXCD = 8;
+
+template <typename real, int BITMASK>
+__global__ __launch_bounds__(FORCE_BLOCK) void k_lj_force_nbr(int n, int n_owned, int nblocks_per_xcd,
+                                                              AtomView<real> atoms, const int *__restrict__ perm,
+                                                              const int *__restrict__ nbr, int stride,
+                                                              const int *__restrict__ cnt, GridP<real> g,
+                                                              LJModel<real> model, size_t pitch,
+                                                              real *__restrict__ frc, real *__restrict__ en,
+                                                              real *__restrict__ vir) {
+    __shared__ real s_out[5][FORCE_ATOMS];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs
+    const int lb = (blockIdx.x % NXCD) * nblocks_per_xcd + blockIdx.x / NXCD;
+    const int first = lb * FORCE_ATOMS;
+    if (first >= n) return;
+    constexpr int PER_WAVE = FORCE_ATOMS / (FORCE_BLOCK / WAVE);
+
+    for (int a = 0; a < PER_WAVE; a++) {
+        const int slot = wv * PER_WAVE + a;
+        const int p = first + slot;
+        if (p >= n) break;
+        real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
+        if (perm[p] < n_owned) {
+            real xi, yi, zi, hs_i, te_i;
+            load_atom(atoms, p, xi, yi, zi, hs_i, te_i);
+            const int m = cnt[p];
+            const int *row = nbr + (size_t)p * stride;
+            for (int k = lane; k < m; k += WAVE) {
+                const int j = row[k];
+                real xj, yj, zj, hs_j, te_j;
+                load_atom(atoms, j, xj, yj, zj, hs_j, te_j);
+                const real dx = min_image(xi - xj, g.plen[0], g.pinv[0]);
+                const real dy = min_image(yi - yj, g.plen[1], g.pinv[1]);
+                const real dz = min_image(zi - zj, g.plen[2], g.pinv[2]);
+                const real r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 < model.rc2) {   // strict test (Q2): listed-but-outside pairs cost nothing more
+                    const real inv_r2 = fast_rcp(r2);
+                    real E, W;
+                    lj_interaction(r2, inv_r2, model, hs_i, te_i, hs_j, te_j, E, W);
+                    if (BITMASK & EMDEE_FORCES) {
+                        const real wr2 = W * inv_r2;   // src/nonbonded.jl:139
+                        fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
+                    }
+                    if (BITMASK & EMDEE_ENERGIES) e += E;
+                    if (BITMASK & EMDEE_VIRIALS) w += W;
+                }
+            }
+            if (BITMASK & EMDEE_FORCES) {
+                fx = wave_sum_to_lane63(fx); fy = wave_sum_to_lane63(fy); fz = wave_sum_to_lane63(fz);
+            }
+            if (BITMASK & EMDEE_ENERGIES) e = wave_sum_to_lane63(e);
+            if (BITMASK & EMDEE_VIRIALS) w = wave_sum_to_lane63(w);
+        }
+        if (lane == WAVE - 1) {
+            s_out[0][slot] = fx; s_out[1][slot] = fy; s_out[2][slot] = fz;
+            s_out[3][slot] = (real)0.5 * e;   // half of each pair term per atom, src/nonbonded.jl:142-145
+            s_out[4][slot] = (real)0.5 * w;
+        }
+    }
+    __syncthreads();
+    const int t = threadIdx.x, col = t & (FORCE_ATOMS - 1), plane = t / FORCE_ATOMS;   // 4 planes of 64 threads
+    if (first + col < n) {
+        if ((BITMASK & EMDEE_FORCES) && plane < 3) frc[plane * pitch + first + col] = s_out[plane][col];
+        if (plane == 3) {
+            if (BITMASK & EMDEE_ENERGIES) en[first + col] = s_out[3][col];
+            if (BITMASK & EMDEE_VIRIALS) vir[first + col] = s_out[4][col];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ integrator
+// verlet_kick_drift: v += c f / m ; x += dt v, one pass (c = dt/2 for a lone half kick, dt when
+// the closing half kick of the previous step is fused in), plus the rebuild trigger:
+// |x - x_build|^2 > (skin/2)^2 raises *flag.
+template <typename real>
+__global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__restrict__ perm, Rec<real> *__restrict__ rec,
+                             real *__restrict__ vel, const real *__restrict__ frc, const real *__restrict__ inv_mass,
+                             real c, real dt, const real *__restrict__ xb, real thr2, int *__restrict__ flag) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (perm[p] >= n_owned) return;
+    Rec<real> r = rec[p];
+    const real cm = inv_mass ? c * inv_mass[p] : c;
+    real vx = vel[p] + cm * frc[p];
+    real vy = vel[pitch + p] + cm * frc[pitch + p];
+    real vz = vel[2 * pitch + p] + cm * frc[2 * pitch + p];
+    vel[p] = vx; vel[pitch + p] = vy; vel[2 * pitch + p] = vz;
+    r.x += dt * vx; r.y += dt * vy; r.z += dt * vz;
+    rec[p] = r;
+    const real dx = r.x - xb[p], dy = r.y - xb[pitch + p], dz = r.z - xb[2 * pitch + p];
+    if (dx * dx + dy * dy + dz * dz > thr2) *flag = 1;
+}
+
+// verlet_kick: v += c f / m
+template <typename real>
+__global__ void k_kick(int n, int n_owned, size_t pitch, const int *__restrict__ perm, real *__restrict__ vel,
+                       const real *__restrict__ frc, const real *__restrict__ inv_mass, real c) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (perm[p] >= n_owned) return;
+    const real cm = inv_mass ? c * inv_mass[p] : c;
+    vel[p] += cm * frc[p];
+    vel[pitch + p] += cm * frc[pitch + p];
+    vel[2 * pitch + p] += cm * frc[2 * pitch + p];
+}
+
+// ------------------------------------------------------------------------------------ caller-order copies
+template <typename real>
+__global__ void k_unsort(int n_owned, int n_total, size_t pitch, const int *__restrict__ inv_perm,
+                         const Rec<real> *__restrict__ rec, const real *__restrict__ vel, const real *__restrict__ frc,
+                         const real *__restrict__ en, const real *__restrict__ vir, real *__restrict__ pos_out,
+                         real *__restrict__ vel_out, real *__restrict__ frc_out, real *__restrict__ en_out,
+                         real *__restrict__ vir_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    int p = inv_perm[i];
+    if (pos_out) {
+        Rec<real> r = rec[p];
+        pos_out[3 * (size_t)i] = r.x; pos_out[3 * (size_t)i + 1] = r.y; pos_out[3 * (size_t)i + 2] = r.z;
+    }
+    if (i >= n_owned) return;
+    if (vel_out) for (int d = 0; d < 3; d++) vel_out[3 * (size_t)i + d] = vel[d * pitch + p];
+    if (frc_out) for (int d = 0; d < 3; d++) frc_out[3 * (size_t)i + d] = frc[d * pitch + p];
+    if (en_out) en_out[i] = en[p];
+    if (vir_out) vir_out[i] = vir[p];
+}
+
+// halo exchange helpers: gather positions (+ periodic shift) of listed caller ids;
+// scatter received positions into ghost records
+template <typename real>
+__global__ void k_pack_positions(int n, const int *__restrict__ ids, const int *__restrict__ inv_perm,
+                                 const Rec<real> *__restrict__ rec, real sx, real sy, real sz, real *__restrict__ buf) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Rec<real> r = rec[inv_perm[ids[k]]];
+    buf[3 * (size_t)k] = r.x + sx; buf[3 * (size_t)k + 1] = r.y + sy; buf[3 * (size_t)k + 2] = r.z + sz;
+}
+
+template <typename real>
+__global__ void k_unpack_ghosts(int n, int first_id, const int *__restrict__ inv_perm, const real *__restrict__ buf,
+                                Rec<real> *__restrict__ rec) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int p = inv_perm[first_id + k];
+    Rec<real> r = rec[p];
+    r.x = buf[3 * (size_t)k]; r.y = buf[3 * (size_t)k + 1]; r.z = buf[3 * (size_t)k + 2];
+    rec[p] = r;
+}
+
+// ------------------------------------------------------------------------------------ reductions
+// Deterministic two-stage sums in fp64 (mixed precision: fp32 per-atom values, fp64 totals).
+constexpr int RED_BLOCK = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum_to_lane63(v);
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    if (lane == WAVE - 1) sh[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int w = 0; w < RED_BLOCK / WAVE; w++) t += sh[w];
+    __syncthreads();
+    return t;   // valid in thread 0
+}
+
+// partial[b][0..2] = sum e, kinetic energy (with optional pending half kick c f/m), sum w
+template <typename real>
+__global__ __launch_bounds__(RED_BLOCK) void k_energy_partials(int n, int n_owned, size_t pitch,
+                                                                const int *__restrict__ perm,
+                                                                const real *__restrict__ en, const real *__restrict__ vir,
+                                                                const real *__restrict__ vel, const real *__restrict__ frc,
+                                                                const real *__restrict__ inv_mass, real c,
+                                                                double *__restrict__ partial) {
+    __shared__ double sh[RED_BLOCK / WAVE];
+    double se = 0.0, sk = 0.0, sw = 0.0;
+    for (int p = blockIdx.x * RED_BLOCK + threadIdx.x; p < n; p += gridDim.x * RED_BLOCK) {
+        if (perm[p] >= n_owned) continue;
+        if (en) se += (double)en[p];
+        if (vir) sw += (double)vir[p];
+        if (vel) {
+            const real im = inv_mass ? inv_mass[p] : (real)1;
+            double k2 = 0.0;
+            for (int d = 0; d < 3; d++) {
+                double v = (double)vel[d * pitch + p] + (double)(c * im) * (double)frc[d * pitch + p];
+                k2 += v * v;
+            }
+            sk += 0.5 * k2 / (double)im;
+        }
+    }
+    double t;
+    t = block_sum(se, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x] = t;
+    t = block_sum(sk, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x + 1] = t;
+    t = block_sum(sw, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x + 2] = t;
+}
+
+static __global__ __launch_bounds__(RED_BLOCK) void k_final_sum3(int nblocks, const double *__restrict__ partial,
+                                                          double *__restrict__ out) {
+    __shared__ double sh[RED_BLOCK / WAVE];
+    for (int q = 0; q < 3; q++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += RED_BLOCK) s += partial[3 * b + q];
+        double t = block_sum(s, sh);
+        if (threadIdx.x == 0) out[q] = t;
+    }
+}
+
+// list statistics: out[0] = entries, out[1] = max row, out[2] = entries with r2 < rc2
+template <typename real>
+__global__ __launch_bounds__(RED_BLOCK) void k_list_stats(int n, AtomView<real> atoms, const int *__restrict__ nbr,
+                                                          int stride, const int *__restrict__ cnt, GridP<real> g,
+                                                          real rc2, int count_pairs,
+                                                          unsigned long long *__restrict__ out) {
+    unsigned long long entries = 0, inside = 0;
+    int mx = 0;
+    for (int p = blockIdx.x * RED_BLOCK + threadIdx.x; p < n; p += gridDim.x * RED_BLOCK) {
+        int m = cnt[p];
+        entries += (unsigned long long)m;
+        mx = max(mx, m);
+        if (count_pairs) {
+            real xi, yi, zi, h, t;
+            load_atom(atoms, p, xi, yi, zi, h, t);
+            for (int k = 0; k < m; k++) {
+                real xj, yj, zj;
+                load_atom(atoms, nbr[(size_t)p * stride + k], xj, yj, zj, h, t);
+                real dx = min_image(xi - xj, g.plen[0], g.pinv[0]);
+                real dy = min_image(yi - yj, g.plen[1], g.pinv[1]);
+                real dz = min_image(zi - zj, g.plen[2], g.pinv[2]);
+                inside += (dx * dx + dy * dy + dz * dz < rc2) ? 1ull : 0ull;
+            }
+        }
+    }
+    atomicAdd(&out[0], entries);   // one integer atomic per thread of a <=1024-block grid: exact, order-free
+    atomicMax(&out[1], (unsigned long long)mx);
+    atomicAdd(&out[2], inside);
+}
+
+}  // namespace emdee

@@ -1,0 +1,351 @@
+// nbsys.hpp -- host-side driver of the cell-ordered system: owns the HBM buffers and enqueues
+// the kernels of kernels.hpp on the context's stream.  Instantiated for float and double.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+
+#include "kernels.hpp"
+
+namespace emdee {
+
+enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_COUNT = 4 };
+
+// in-place exclusive scan of int32 data[0..n) (n may exceed one tile: recursive tile sums)
+struct Scanner {
+    DevBuf<int> scratch;
+    void run(int *data, size_t n, hipStream_t s) {
+        if (n == 0) return;
+        size_t total = 0;
+        for (size_t m = n; m > 1;) {
+            m = (m + SCAN_TILE - 1) / SCAN_TILE;
+            total += m;
+            if (m == 1) break;
+        }
+        scratch.ensure(total + 1);
+        level(data, n, scratch.ptr, s);
+    }
+
+  private:
+    void level(int *data, size_t n, int *sums, hipStream_t s) {
+        size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, data, data, n,
+                           tiles > 1 ? sums : nullptr);
+        if (tiles > 1) {
+            level(sums, tiles, sums + tiles, s);
+            hipLaunchKernelGGL(k_scan_add, dim3(blocks_for(n, 256)), dim3(256), 0, s, data, n, sums);
+        }
+    }
+};
+
+template <typename real>
+struct NbSystem {
+    emdee_ctx *ctx = nullptr;
+    double lo[3] = {0, 0, 0}, len[3] = {0, 0, 0};
+    int per[3] = {1, 1, 1};
+    double skin = 0.3, rlist = 0.0;
+    int ndiv = 1;
+    emdee_lj_model model_d{};
+    LJModel<real> model{};
+    GridP<real> grid{};
+    size_t ncell = 0;
+    int n_total = 0, n_owned = 0;
+    size_t pitch = 0;
+    bool with_vel = false, with_mass = false;
+    bool sorted = false, has_list = false;
+    int stride = 0;
+    int64_t builds = 0;
+    bool profiling = false;
+    KernelTimer timers[T_COUNT];
+
+    DevBuf<Rec<real>> rec, rec2;
+    DevBuf<float> te, te2;
+    DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb;
+    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags;
+    DevBuf<double> partial, sums;
+    DevBuf<unsigned long long> stats;
+    Scanner scanner;
+
+    hipStream_t stream() const { return ctx->stream; }
+    AtomView<real> view() const { return AtomView<real>{rec.ptr, te.ptr}; }
+
+    struct Timed {
+        NbSystem *s;
+        int id;
+        size_t k = 0;
+        Timed(NbSystem *sys, int which) : s(sys), id(which) {
+            if (s->profiling) k = s->timers[id].begin(s->stream());
+        }
+        ~Timed() {
+            if (s->profiling) s->timers[id].end(k, s->stream());
+        }
+    };
+
+    // ---------------------------------------------------------------- geometry
+    void set_box(const double lo_[3], const double len_[3], const int per_[3]) {
+        bool same = true;
+        for (int d = 0; d < 3; d++) same = same && lo[d] == lo_[d] && len[d] == len_[d] && per[d] == (per_[d] ? 1 : 0);
+        if (!same) sorted = has_list = false;
+        for (int d = 0; d < 3; d++) {
+            lo[d] = lo_[d]; len[d] = len_[d]; per[d] = per_[d] ? 1 : 0;
+            EMDEE_REQUIRE(len[d] > 0.0 && std::isfinite(len[d]), EMDEE_ERR_INVALID, "box length must be positive");
+        }
+    }
+
+    void set_model(const emdee_lj_model &m, double skin_) {
+        EMDEE_REQUIRE(m.rc2 > 0 && m.rs2 >= 0 && m.rs2 < m.rc2 && std::isfinite(m.inv_delta2), EMDEE_ERR_INVALID,
+                      "LennardJonesModel needs 0 <= switch < cutoff (Q10: switch == cutoff gives 1/0)");
+        EMDEE_REQUIRE(skin_ >= 0.0, EMDEE_ERR_INVALID, "skin must be >= 0");
+        if (m.rc2 != model_d.rc2 || skin_ != skin) has_list = sorted = false;
+        model_d = m;
+        model = make_model<real>(m);
+        skin = skin_;
+        rlist = std::sqrt(m.rc2) + skin;
+    }
+
+    void configure_grid() {
+        GridP<real> g{};
+        size_t cells = 1;
+        int M[3];
+        for (int d = 0; d < 3; d++) {
+            if (per[d])
+                EMDEE_REQUIRE(rlist <= 0.5 * len[d], EMDEE_ERR_INVALID,
+                              "cutoff + skin = %g exceeds half the periodic box length %g (minimum image)", rlist, len[d]);
+            M[d] = std::max(1, (int)std::floor(len[d] * ndiv / rlist));
+            M[d] = std::min(M[d], 1024);
+        }
+        // sparse boxes: never more cells than ~4 per atom (larger cells stay valid)
+        while ((size_t)M[0] * M[1] * M[2] > 4 * (size_t)std::max(n_total, 16) + 64) {
+            int big = 0;
+            for (int d = 1; d < 3; d++)
+                if (M[d] > M[big]) big = d;
+            if (M[big] <= 1) break;
+            M[big] = (M[big] + 1) / 2;
+        }
+        for (int d = 0; d < 3; d++) {
+            g.lo[d] = (real)lo[d]; g.len[d] = (real)len[d];
+            g.plen[d] = per[d] ? (real)len[d] : (real)0;
+            g.pinv[d] = per[d] ? (real)(1.0 / len[d]) : (real)0;
+            g.per[d] = per[d];
+            g.M[d] = M[d];
+            cells *= (size_t)M[d];
+        }
+        g.nd = ndiv;
+        g.one_based = 0;
+        grid = g;
+        ncell = cells;
+    }
+
+    void reserve(int n, bool velocities, bool masses) {
+        n_total = n;
+        pitch = ((size_t)n + 63) / 64 * 64 + 64;
+        with_vel = velocities;
+        with_mass = masses;
+        rec.ensure(n + 1); rec2.ensure(n + 1);
+        if (sizeof(real) == 4) { te.ensure(n + 1); te2.ensure(n + 1); }
+        frc.ensure(3 * pitch); en.ensure(pitch); vir.ensure(pitch); xb.ensure(3 * pitch);
+        if (velocities) { vel.ensure(3 * pitch); vel2.ensure(3 * pitch); }
+        if (masses) { im.ensure(pitch); im2.ensure(pitch); }
+        perm.ensure(n + 1); perm2.ensure(n + 1); inv_perm.ensure(n + 1);
+        cell_of.ensure(n + 1); cell_sorted.ensure(n + 1); order.ensure(n + 1); tmp.ensure(n + 1); cnt.ensure(n + 1);
+        if (flags.ensure(16)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 16 * sizeof(int), stream()));
+        partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
+    }
+
+    // ---------------------------------------------------------------- binning
+    template <class Src>
+    void bin(Src src, const int *key) {
+        const int n = n_total;
+        count.ensure(ncell + 2); fill.ensure(ncell + 2);
+        EMDEE_HIP_CHECK(hipMemsetAsync(count.ptr, 0, (ncell + 1) * sizeof(int), stream()));
+        EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, ncell * sizeof(int), stream()));
+        if (n == 0) return;
+        hipLaunchKernelGGL((k_cell_assign<real, Src>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
+                           cell_of.ptr, count.ptr);
+        scanner.run(count.ptr, ncell + 1, stream());   // count[] becomes start[]
+        hipLaunchKernelGGL(k_cell_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, 0, count.ptr,
+                           fill.ptr, tmp.ptr);
+        hipLaunchKernelGGL(k_cell_rankfix, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, 0, count.ptr,
+                           tmp.ptr, key, order.ptr);
+    }
+    const int *start() const { return count.ptr; }
+
+    // caller-order arrays -> cell-ordered state (+ list)
+    void load_user(int n_own, int n_ghost, const real *pos, const real *velocities, const emdee_lj_atom *atoms,
+                   const real *inv_mass) {
+        EMDEE_REQUIRE(n_own >= 0 && n_ghost >= 0, EMDEE_ERR_INVALID, "negative atom count");
+        EMDEE_REQUIRE((int64_t)n_own + n_ghost < (int64_t)1 << 31, EMDEE_ERR_INVALID, "too many atoms");
+        EMDEE_REQUIRE(n_own + n_ghost == 0 || (pos && atoms), EMDEE_ERR_INVALID, "positions/atoms are NULL");
+        Timed t(this, T_REBUILD);
+        n_owned = n_own;
+        reserve(n_own + n_ghost, velocities != nullptr || with_vel, inv_mass != nullptr);
+        configure_grid();
+        const int n = n_total;
+        bin(UserPos<real>{pos}, nullptr);
+        if (n > 0)
+            hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
+                               order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
+                               with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
+                               cell_sorted.ptr);
+        sorted = true;
+        build_list();
+    }
+
+    // re-bin / re-sort the current state (MD rebuild)
+    void resort() {
+        EMDEE_REQUIRE(sorted, EMDEE_ERR_STATE, "no state loaded");
+        Timed t(this, T_REBUILD);
+        const int n = n_total;
+        configure_grid();
+        bin(RecPos<real>{rec.ptr}, perm.ptr);
+        if (n > 0)
+            hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch,
+                               order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
+                               with_mass ? im.ptr : nullptr, perm.ptr, rec2.ptr, te2.ptr, xb.ptr,
+                               with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
+                               cell_sorted.ptr);
+        rec.swap(rec2); te.swap(te2); perm.swap(perm2);
+        if (with_vel) vel.swap(vel2);
+        if (with_mass) im.swap(im2);
+        build_list();
+    }
+
+    // ---------------------------------------------------------------- neighbour list
+    void build_list() {
+        const int n = n_total;
+        if (stride == 0) {
+            double vol = len[0] * len[1] * len[2];
+            double expect = n > 0 ? (4.0 / 3.0) * M_PI * rlist * rlist * rlist * (double)n / vol : 0.0;
+            stride = (int)((expect * 1.3 + 24.0) / 16.0 + 1.0) * 16;
+        }
+        for (int attempt = 0; attempt < 6; attempt++) {
+            EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
+            nbr.ensure((size_t)std::max(n, 1) * stride);
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 2 * sizeof(int), stream()));
+            if (n > 0)
+                hipLaunchKernelGGL((k_nbr_build<real>), dim3(blocks_for((size_t)n * WAVE, NBR_BLOCK)), dim3(NBR_BLOCK), 0,
+                                   stream(), n, n_owned, view(), perm.ptr, cell_sorted.ptr, start(), grid,
+                                   (real)(rlist * rlist), nbr.ptr, stride, cnt.ptr, flags.ptr);
+            // a build is rare (every ~10-20 steps): one blocking read-back of the overflow word
+            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+            int needed = ctx->host_flags[0];
+            if (needed <= stride) {
+                builds++;
+                has_list = true;
+                return;
+            }
+            stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
+        }
+        EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
+    }
+
+    // ---------------------------------------------------------------- forces
+    template <int BM>
+    void launch_force() {
+        const int n = n_total;
+        int nblocks = (n + FORCE_ATOMS - 1) / FORCE_ATOMS;
+        int per_xcd = (nblocks + NXCD - 1) / NXCD;
+        hipLaunchKernelGGL((k_lj_force_nbr<real, BM>), dim3(per_xcd * NXCD), dim3(FORCE_BLOCK), 0, stream(), n, n_owned,
+                           per_xcd, view(), perm.ptr, nbr.ptr, stride, cnt.ptr, grid, model, pitch, frc.ptr, en.ptr,
+                           vir.ptr);
+    }
+
+    void compute_forces(int bitmask) {
+        EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
+        EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of 1|2|4");
+        if (n_total == 0 || bitmask == 0) return;
+        Timed t(this, T_FORCE);
+        switch (bitmask) {
+            case 1: launch_force<1>(); break;
+            case 2: launch_force<2>(); break;
+            case 3: launch_force<3>(); break;
+            case 4: launch_force<4>(); break;
+            case 5: launch_force<5>(); break;
+            case 6: launch_force<6>(); break;
+            default: launch_force<7>(); break;
+        }
+    }
+
+    // ---------------------------------------------------------------- integrator
+    void kick_drift(double c, double dt) {
+        EMDEE_REQUIRE(sorted && with_vel, EMDEE_ERR_STATE, "no velocities loaded");
+        if (n_total == 0) return;
+        Timed t(this, T_KICK_DRIFT);
+        real thr = (real)(0.5 * skin);
+        hipLaunchKernelGGL((k_kick_drift<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
+                           pitch, perm.ptr, rec.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c, (real)dt,
+                           xb.ptr, thr * thr, flags.ptr + 1);
+    }
+
+    void kick(double c) {
+        EMDEE_REQUIRE(sorted && with_vel, EMDEE_ERR_STATE, "no velocities loaded");
+        if (n_total == 0) return;
+        Timed t(this, T_KICK);
+        hipLaunchKernelGGL((k_kick<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned, pitch,
+                           perm.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c);
+    }
+
+    // blocking read of the rebuild trigger raised by kick_drift / check_user_displacement
+    bool read_rebuild_flag() {
+        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 1, flags.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        return ctx->host_flags[1] != 0;
+    }
+
+    // ---------------------------------------------------------------- observables
+    // out[0] = sum e, out[1] = kinetic energy (velocities advanced by a pending c f/m), out[2] = sum w
+    void energy_sums(double pending_c, double out[3]) {
+        out[0] = out[1] = out[2] = 0.0;
+        if (n_total == 0) return;
+        int nb = std::min((int)blocks_for(n_total, RED_BLOCK), RED_MAX_BLOCKS);
+        hipLaunchKernelGGL((k_energy_partials<real>), dim3(nb), dim3(RED_BLOCK), 0, stream(), n_total, n_owned, pitch,
+                           perm.ptr, en.ptr, vir.ptr, with_vel ? vel.ptr : nullptr, frc.ptr,
+                           with_mass ? im.ptr : nullptr, (real)pending_c, partial.ptr);
+        hipLaunchKernelGGL(k_final_sum3, dim3(1), dim3(RED_BLOCK), 0, stream(), nb, partial.ptr, sums.ptr);
+        EMDEE_HIP_CHECK(hipMemcpyAsync(out, sums.ptr, 3 * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+
+    void list_stats(bool count_pairs, int64_t *listed, int32_t *max_count, int64_t *inside) {
+        unsigned long long h[3] = {0, 0, 0};
+        if (has_list && n_total > 0) {
+            EMDEE_HIP_CHECK(hipMemsetAsync(stats.ptr, 0, 3 * sizeof(unsigned long long), stream()));
+            int nb = std::min((int)blocks_for(n_total, RED_BLOCK), RED_MAX_BLOCKS);
+            hipLaunchKernelGGL((k_list_stats<real>), dim3(nb), dim3(RED_BLOCK), 0, stream(), n_total, view(), nbr.ptr,
+                               stride, cnt.ptr, grid, model.rc2, count_pairs ? 1 : 0, stats.ptr);
+            EMDEE_HIP_CHECK(hipMemcpyAsync(h, stats.ptr, sizeof(h), hipMemcpyDeviceToHost, stream()));
+            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        }
+        if (listed) *listed = (int64_t)h[0];
+        if (max_count) *max_count = (int32_t)h[1];
+        if (inside) *inside = (int64_t)(h[2] / 2);   // full list: every pair appears twice
+    }
+
+    // ---------------------------------------------------------------- caller-order copies
+    void unsort(real *pos, real *velocities, real *forces, real *energies, real *virials) {
+        if (n_total == 0) return;
+        EMDEE_REQUIRE(!velocities || with_vel, EMDEE_ERR_STATE, "no velocities loaded");
+        hipLaunchKernelGGL((k_unsort<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_owned, n_total, pitch,
+                           inv_perm.ptr, rec.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr, pos, velocities,
+                           forces, energies, virials);
+    }
+
+    // operator path: does the cached list still cover these caller positions?
+    bool user_positions_moved(const real *pos) {
+        if (n_total == 0) return false;
+        real thr = (real)(0.5 * skin);
+        EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 1, 0, sizeof(int), stream()));
+        hipLaunchKernelGGL((k_check_displacement<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
+                           inv_perm.ptr, pos, xb.ptr, pitch, grid, thr * thr, flags.ptr + 1);
+        return read_rebuild_flag();
+    }
+
+    void refresh_user(const real *pos, const emdee_lj_atom *atoms) {
+        if (n_total == 0) return;
+        hipLaunchKernelGGL((k_refresh_positions<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
+                           perm.ptr, pos, atoms, rec.ptr, te.ptr);
+    }
+};
+
+}  // namespace emdee

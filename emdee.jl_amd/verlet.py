@@ -1,0 +1,133 @@
+"""Velocity-Verlet on the device.  Build-defined: the reference has no integrator (SURVEY.md 8a
+row a16); the API follows EmDee's operator style (constructor + `!` mutators spelled `_`)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .device import check_array, context_for, precision_of
+from .nonbonded import ENERGIES, FORCES, VIRIALS
+
+KERNELS = {"lj_force_nbr": 0, "verlet_kick_drift": 1, "rebuild": 2, "verlet_kick": 3}
+
+
+class VelocityVerlet:
+    """v += (dt/2m) f ; x += dt v ; f = F(x) ; v += (dt/2m) f, with the state kept in cell order in
+    HBM between steps.  positions (n_owned + n_ghost, 3), velocities (n_owned, 3), atoms
+    (n_owned + n_ghost, 2) float32 [LJAtom], inv_mass (n_owned,) or None (m = 1).
+
+    Single-GPU, reference-shaped box: VelocityVerlet(x, v, L, model, atoms).
+    Domain-decomposed: pass lo/lengths/periodic and n_ghost, and drive kick_drift_/forces_/kick_."""
+
+    def __init__(self, positions, velocities, L, model, atoms, skin=0.3, inv_mass=None, lo=None, lengths=None,
+                 periodic=None, n_ghost=0):
+        n_total = positions.shape[0]
+        n_owned = n_total - int(n_ghost)
+        dev, dt = positions.device, positions.dtype
+        self.n_owned, self.n_ghost, self.device, self.dtype = n_owned, int(n_ghost), dev, dt
+        self.model = model
+        self._ctx = context_for(dev)
+        lo = [0.0, 0.0, 0.0] if lo is None else [float(v) for v in lo]
+        lengths = [float(L)] * 3 if lengths is None else [float(v) for v in lengths]
+        periodic = [1, 1, 1] if periodic is None else [int(bool(v)) for v in periodic]
+        self.lo, self.lengths, self.periodic = lo, lengths, periodic
+        h = C.c_void_p()
+        _lib.call("emdee_md_create", self._ctx.handle, (C.c_double * 3)(*lo), (C.c_double * 3)(*lengths),
+                  (C.c_int32 * 3)(*periodic), _lib.model_c(model), float(skin), precision_of(positions), C.byref(h))
+        self._handle = h
+        self.set_state_(positions, velocities, atoms, inv_mass, n_ghost)
+
+    def set_state_(self, positions, velocities, atoms, inv_mass=None, n_ghost=0):
+        n_total = positions.shape[0]
+        n_owned = n_total - int(n_ghost)
+        check_array(positions, "positions", n_total, 3, self.dtype, self.device)
+        check_array(velocities, "velocities", n_owned, 3, self.dtype, self.device)
+        check_array(atoms, "atoms", n_total, 2, torch.float32, self.device)
+        if inv_mass is not None:
+            check_array(inv_mass, "inv_mass", n_owned, None, self.dtype, self.device)
+        self.n_owned, self.n_ghost = n_owned, int(n_ghost)
+        _lib.call("emdee_md_set_state", self._handle, n_owned, int(n_ghost), C.c_void_p(positions.data_ptr()),
+                  C.c_void_p(velocities.data_ptr()), C.c_void_p(atoms.data_ptr()),
+                  C.c_void_p(inv_mass.data_ptr()) if inv_mass is not None else None)
+
+    # -- whole steps (single domain)
+    def step_(self, nsteps, dt, rebuild_every=0):
+        _lib.call("emdee_md_step", self._handle, int(nsteps), float(dt), int(rebuild_every))
+
+    # -- split step (domain-decomposed driver: kick_drift_ -> halo exchange -> forces_ -> kick_)
+    def kick_drift_(self, dt):
+        _lib.call("emdee_md_kick_drift", self._handle, float(dt))
+
+    def forces_(self, bitmask=FORCES):
+        _lib.call("emdee_md_forces", self._handle, int(bitmask))
+
+    def kick_(self, dt):
+        _lib.call("emdee_md_kick", self._handle, float(dt))
+
+    def needs_rebuild(self):
+        f = C.c_int32()
+        _lib.call("emdee_md_needs_rebuild", self._handle, C.byref(f))
+        return bool(f.value)
+
+    def rebuild_(self):
+        _lib.call("emdee_md_rebuild", self._handle)
+
+    def pack_positions(self, ids, shift, out=None):
+        n = ids.shape[0]
+        if out is None:
+            out = torch.empty((n, 3), dtype=self.dtype, device=self.device)
+        _lib.call("emdee_md_pack_positions", self._handle, C.c_void_p(ids.data_ptr()), n,
+                  (C.c_double * 3)(*[float(s) for s in shift]), C.c_void_p(out.data_ptr()))
+        return out
+
+    def unpack_ghosts_(self, buf, first):
+        _lib.call("emdee_md_unpack_ghosts", self._handle, C.c_void_p(buf.data_ptr()), int(first), buf.shape[0])
+
+    # -- state back in caller order
+    def state(self, positions=True, velocities=True, forces=True, energies=False, virials=False):
+        n, nt = self.n_owned, self.n_owned + self.n_ghost
+        mk = lambda rows, cols: torch.empty((rows, cols) if cols else (rows,), dtype=self.dtype, device=self.device)
+        out = dict(positions=mk(nt, 3) if positions else None, velocities=mk(n, 3) if velocities else None,
+                   forces=mk(n, 3) if forces else None, energies=mk(n, 0) if energies else None,
+                   virials=mk(n, 0) if virials else None)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.call("emdee_md_get_state", self._handle, p(out["positions"]), p(out["velocities"]), p(out["forces"]),
+                  p(out["energies"]), p(out["virials"]))
+        return out
+
+    def totals(self):
+        """(potential energy, kinetic energy, virial sum) over owned atoms; fp64 reduction (blocking)."""
+        out = (C.c_double * 3)()
+        _lib.call("emdee_md_energies", self._handle, out)
+        return out[0], out[1], out[2]
+
+    def nbr_stats(self):
+        b, l, m, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _lib.call("emdee_md_nbr_stats", self._handle, C.byref(b), C.byref(l), C.byref(m), C.byref(c))
+        return dict(builds=b.value, listed=l.value, max_count=m.value, capacity=c.value)
+
+    def count_pairs(self):
+        n = C.c_int64()
+        _lib.call("emdee_md_count_pairs", self._handle, C.byref(n))
+        return n.value
+
+    def profile_(self, enable=True):
+        _lib.call("emdee_md_profile", self._handle, int(bool(enable)))
+
+    def kernel_time(self, kernel):
+        """(total device ms, launches) of a kernel since profile_(True): HIP events on the stream."""
+        ms, k = C.c_double(), C.c_int64()
+        _lib.call("emdee_md_kernel_time", self._handle, KERNELS[kernel] if isinstance(kernel, str) else int(kernel),
+                  C.byref(ms), C.byref(k))
+        return ms.value, k.value
+
+    def close(self):
+        if self._handle is not None:
+            _lib.call("emdee_md_destroy", self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

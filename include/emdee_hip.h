@@ -1,0 +1,217 @@
+/*
+ * emdee_hip.h -- C ABI of libemdee_hip.so: the MI355X (gfx950) implementation of
+ * EmDee.jl's nonbonded pair-force hot path (cell-list neighbour build, switched
+ * Lennard-Jones force / per-atom energy / per-atom virial, velocity-Verlet).
+ *
+ * This is the drop-in boundary.  EmDee's Julia operator layer (src/lennard_jones.jl,
+ * src/nonbonded.jl, src/cells.jl of the reference) binds these symbols with `ccall`
+ * in place of its CUDA.jl kernels; INTEGRATION.md shows that binding, and
+ * emdee.jl_amd/ mirrors the same operator API in Python over ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - Every call returns int32 status: 0 = EMDEE_OK, negative = error; the message of
+ *     the last error on the calling thread is emdee_last_error().  No exception crosses.
+ *   - Handles are opaque, owned by the library, freed by the matching *_destroy.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (hipMalloc,
+ *     emdee_malloc or a torch tensor's data_ptr) on the context's device.
+ *   - Work is enqueued on the context's HIP stream; emdee_sync() and the calls that
+ *     return host values are the only blocking calls.  One host thread per context,
+ *     as in the reference (single-threaded host, async launches, src/nonbonded.jl:115-119).
+ *   - Arrays follow the reference: positions/forces/velocities are 3xN column-major
+ *     (xyz interleaved, src/nonbonded.jl:52-61), energies/virials length N.
+ *   - precision = bytes per real of the caller's arrays: EMDEE_F32 (the reference's
+ *     Float32) or EMDEE_F64 (north-star fp64).  Pair math runs in that type.
+ *   - Pair semantics are the reference formula src/lennard_jones.jl:25-42.  The O(N)
+ *     path drops pairs with r^2 >= rc^2 (EMDEE_CUTOFF); the all-pairs entry points can
+ *     also reproduce the reference's literal behaviour, where the switch clamp gives
+ *     g = 1 (full LJ) beyond rc (EMDEE_LITERAL).
+ */
+#ifndef EMDEE_HIP_H
+#define EMDEE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMDEE_VERSION 100            /* 0.1.0, tracks the reference's Project.toml:4 */
+
+/* status codes */
+#define EMDEE_OK                 0
+#define EMDEE_ERR_INVALID       -1   /* bad argument */
+#define EMDEE_ERR_HIP           -2   /* HIP runtime error (message has hipGetErrorString) */
+#define EMDEE_ERR_NO_DEVICE     -3   /* no usable gfx950 device */
+#define EMDEE_ERR_ALLOC         -4
+#define EMDEE_ERR_OVERFLOW      -5   /* neighbour capacity could not be grown */
+#define EMDEE_ERR_STATE         -6   /* call out of order (e.g. step before set_state) */
+
+/* output-selection bitmask -- src/nonbonded.jl:12-14 */
+#define EMDEE_FORCES    1
+#define EMDEE_ENERGIES  2
+#define EMDEE_VIRIALS   4
+
+/* precision = sizeof(real) */
+#define EMDEE_F32 4
+#define EMDEE_F64 8
+
+/* pair semantics beyond the cutoff (all-pairs entry points only) */
+#define EMDEE_LITERAL 0
+#define EMDEE_CUTOFF  1
+
+/* LennardJonesModel -- src/lennard_jones.jl:6-11: {rc^2, rs^2, 1/(rc^2 - rs^2)}.
+ * Passed by value as doubles; the EMDEE_F32 path rounds each field to float first,
+ * which is exactly the reference's Float32 struct. */
+typedef struct emdee_lj_model { double rc2, rs2, inv_delta2; } emdee_lj_model;
+
+/* LJAtom -- src/lennard_jones.jl:15-18, identical layout (2 x Float32, 8 bytes).
+ * sigma_ij = half_sigma_i + half_sigma_j, 4 eps_ij = twice_sqrt_eps_i * twice_sqrt_eps_j
+ * (Lorentz-Berthelot), src/lennard_jones.jl:29-30. */
+typedef struct emdee_lj_atom { float half_sigma, twice_sqrt_eps; } emdee_lj_atom;
+
+typedef struct emdee_ctx   emdee_ctx;     /* device + stream                      (replaces CUDA.jl context handling) */
+typedef struct emdee_cells emdee_cells;   /* Cells                                (src/cells.jl:6-20) */
+typedef struct emdee_nbr   emdee_nbr;     /* neighbour handle carried by `tiles`  (src/nonbonded.jl:18-26) */
+typedef struct emdee_md    emdee_md;      /* velocity-Verlet state                (absent from the reference) */
+
+/* ---------------------------------------------------------------- context */
+const char *emdee_last_error(void);
+int32_t emdee_version(void);
+int32_t emdee_device_count(int32_t *count);
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL for the
+ * device's default stream. */
+int32_t emdee_ctx_create(int32_t device_id, void *stream, emdee_ctx **out);
+int32_t emdee_ctx_destroy(emdee_ctx *ctx);
+int32_t emdee_sync(emdee_ctx *ctx);
+/* arch name ("gfx950..."), CU count and HBM bytes of the context's device */
+int32_t emdee_device_info(emdee_ctx *ctx, char *arch, size_t arch_len, int32_t *cu_count, int64_t *hbm_bytes);
+
+/* ---------------------------------------------------------------- memory
+ * Replaces CuArray / CUDA.cu / CUDA.zeros / Array(dev) / unsafe_copyto!
+ * (src/nonbonded.jl:25,123,151-153; test/runtests.jl:22-35). */
+int32_t emdee_malloc(emdee_ctx *ctx, size_t nbytes, void **dev);
+int32_t emdee_free(emdee_ctx *ctx, void *dev);
+int32_t emdee_memcpy_h2d(emdee_ctx *ctx, void *dev, const void *host, size_t nbytes);
+int32_t emdee_memcpy_d2h(emdee_ctx *ctx, void *host, const void *dev, size_t nbytes);   /* blocking */
+int32_t emdee_memcpy_d2d(emdee_ctx *ctx, void *dst, const void *src, size_t nbytes);
+int32_t emdee_memset(emdee_ctx *ctx, void *dev, int32_t byte, size_t nbytes);
+
+/* ---------------------------------------------------------------- pair function
+ * interaction(r2, model, atom_i, atom_j) -- src/lennard_jones.jl:25-42, evaluated by the
+ * DEVICE pair function on n values of r2 (dev arrays of `precision` reals): E[k], W[k]. */
+int32_t emdee_interaction(emdee_ctx *ctx, int32_t n, const void *r2_dev, emdee_lj_model model,
+                          emdee_lj_atom atom_i, emdee_lj_atom atom_j, int32_t mode,
+                          void *E_dev, void *W_dev, int32_t precision);
+
+/* ---------------------------------------------------------------- Cells
+ * Cells(r, L, cutoff; ndiv=2) -- src/cells.jl:176-194: M = floor(ndiv L / cutoff) cells per
+ * dimension, 1-based cell id 1 + vx + M vy + M^2 vz, v = floor(M (s - floor s)), s = r / L.
+ * emdee_cells_update = update_cells!(cells, r, L) (src/cells.jl:196-222); it re-bins all
+ * atoms in O(N) (counting sort) instead of the reference's incremental linked-list edit. */
+int32_t emdee_cells_create(emdee_ctx *ctx, int32_t N, double L, double cutoff, int32_t ndiv,
+                           int32_t precision, emdee_cells **out);
+int32_t emdee_cells_update(emdee_cells *cells, const void *positions_dev);
+int32_t emdee_cells_destroy(emdee_cells *cells);
+int32_t emdee_cells_M(const emdee_cells *cells, int32_t *M);
+/* dev pointers valid until the next update/destroy: index[N] (1-based cell of each atom),
+ * population[M^3], start[M^3+1] (0-based offsets into order), order[N] (atom ids by cell,
+ * ascending within a cell -- the array form of the reference's head/next lists). */
+int32_t emdee_cells_arrays(const emdee_cells *cells, const int32_t **index_dev,
+                           const int32_t **population_dev, const int32_t **start_dev,
+                           const int32_t **order_dev);
+
+/* ---------------------------------------------------------------- neighbour handle
+ * nonbonded_computation_tiles(N) (src/nonbonded.jl:18-26) returns what compute_nonbonded!
+ * iterates over.  Here that object is a neighbour-list workspace for N atoms: cell binning,
+ * cell-ordered copies and a full (owner-computes) list with a skin, rebuilt inside
+ * emdee_compute_nonbonded when any atom has moved more than skin/2 since the last build. */
+int32_t emdee_nbr_create(emdee_ctx *ctx, int32_t N, double skin, int32_t precision, emdee_nbr **out);
+int32_t emdee_nbr_destroy(emdee_nbr *nbr);
+/* builds = list builds so far; listed = entries in the current list; max_count = longest
+ * row; capacity = row stride.  Blocking. */
+int32_t emdee_nbr_stats(emdee_nbr *nbr, int64_t *builds, int64_t *listed, int32_t *max_count,
+                        int32_t *capacity);
+/* number of pairs with r^2 < rc^2 in the current list (each pair counted once). Blocking. */
+int32_t emdee_nbr_count_pairs(emdee_nbr *nbr, int64_t *pairs_in_cutoff);
+
+/* compute_nonbonded!(forces, energies, virials, positions, L, tiles, model, atoms, Val(bitmask))
+ * -- src/nonbonded.jl:109-120 -- O(N) neighbour-list path, EMDEE_CUTOFF semantics.
+ * Outputs not selected by bitmask may be NULL and are left untouched; selected outputs are
+ * overwritten (the reference zero-fills then accumulates, src/nonbonded.jl:112-114). */
+int32_t emdee_compute_nonbonded(emdee_ctx *ctx, void *forces_dev, void *energies_dev, void *virials_dev,
+                                const void *positions_dev, double L, emdee_nbr *nbr,
+                                emdee_lj_model model, const emdee_lj_atom *atoms_dev,
+                                int32_t bitmask, int32_t precision);
+
+/* compute_tile! semantics (src/nonbonded.jl:44-107) for any N: all-pairs 64x64 tiles,
+ * one wavefront per tile pair, lane rotation through DPP/bpermute instead of shfl_sync.
+ * mode = EMDEE_LITERAL reproduces the reference operator exactly (Q1). */
+int32_t emdee_compute_nonbonded_tiles(emdee_ctx *ctx, void *forces_dev, void *energies_dev, void *virials_dev,
+                                      const void *positions_dev, double L, int32_t N,
+                                      emdee_lj_model model, const emdee_lj_atom *atoms_dev,
+                                      int32_t bitmask, int32_t mode, int32_t precision);
+
+/* naively_compute_nonbonded!(forces, energies, virials, positions, L, model, atoms)
+ * -- src/nonbonded.jl:122-155 -- the plain double loop, one device thread per atom i over
+ * all j != i (no tiles, no list, no lane exchange); always all three outputs. */
+int32_t emdee_compute_nonbonded_naive(emdee_ctx *ctx, void *forces_dev, void *energies_dev, void *virials_dev,
+                                      const void *positions_dev, double L, int32_t N,
+                                      emdee_lj_model model, const emdee_lj_atom *atoms_dev,
+                                      int32_t mode, int32_t precision);
+
+/* ---------------------------------------------------------------- velocity-Verlet
+ * Build-defined:  v += (dt/2m) f ; x += dt v ; f = F(x) ; v += (dt/2m) f.
+ * The state lives on the device in cell order between calls.  The box is orthorhombic
+ * [lo, lo+len) per dimension; periodic[d] != 0 applies the minimum-image convention along d.
+ * Atoms 0..n_owned-1 are integrated; atoms n_owned..n_owned+n_ghost-1 are ghosts (images
+ * owned by another domain): they act on owned atoms but receive no force and
+ * are moved only by emdee_md_unpack_ghosts.  The single-GPU reference-shaped case is
+ * lo = 0, len = L, periodic = {1,1,1}, n_ghost = 0. */
+int32_t emdee_md_create(emdee_ctx *ctx, const double lo[3], const double len[3], const int32_t periodic[3],
+                        emdee_lj_model model, double skin, int32_t precision, emdee_md **out);
+int32_t emdee_md_destroy(emdee_md *md);
+/* (Re)load the state, in caller order.  velocities_dev has 3 n_owned reals; inv_mass_dev
+ * (n_owned reals) may be NULL for m = 1 (LJAtom has no mass, src/lennard_jones.jl:15-18).
+ * Bins, sorts, builds the neighbour list and evaluates the forces. */
+int32_t emdee_md_set_state(emdee_md *md, int32_t n_owned, int32_t n_ghost, const void *positions_dev,
+                           const void *velocities_dev, const emdee_lj_atom *atoms_dev,
+                           const void *inv_mass_dev);
+/* Copy the state back in caller order; any pointer may be NULL. positions: n_owned+n_ghost
+ * atoms; velocities/forces/energies/virials: n_owned atoms. */
+int32_t emdee_md_get_state(emdee_md *md, void *positions_dev, void *velocities_dev, void *forces_dev,
+                           void *energies_dev, void *virials_dev);
+/* nsteps whole steps (n_ghost must be 0: a decomposed run drives the split calls below).
+ * rebuild_every > 0: fixed cadence; 0: rebuild when max displacement > skin/2. */
+int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every);
+/* split step for domain-decomposed runs:  kick_drift -> [halo exchange] -> forces -> kick */
+int32_t emdee_md_kick_drift(emdee_md *md, double dt);        /* v += (dt/2m) f ; x += dt v (owned) */
+int32_t emdee_md_forces(emdee_md *md, int32_t bitmask);      /* f (and e, w) of owned atoms */
+int32_t emdee_md_kick(emdee_md *md, double dt);              /* v += (dt/2m) f */
+/* 1 if some owned atom moved more than skin/2 since the last build. Blocking. */
+int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag);
+/* re-bin, re-sort and rebuild the neighbour list from the current positions */
+int32_t emdee_md_rebuild(emdee_md *md);
+/* halo: gather positions of the listed atoms (caller-order ids, dev int32[n]) plus a shift
+ * into buf (3 n reals), and scatter received positions into ghost slots first..first+n-1
+ * (ghost-relative). */
+int32_t emdee_md_pack_positions(emdee_md *md, const int32_t *ids_dev, int32_t n, const double shift[3],
+                                void *buf_dev);
+int32_t emdee_md_unpack_ghosts(emdee_md *md, const void *buf_dev, int32_t first, int32_t n);
+/* totals over owned atoms: out[0] = potential energy (sum of per-atom halves), out[1] =
+ * kinetic energy, out[2] = virial sum.  Evaluates energies/virials if needed. Blocking. */
+int32_t emdee_md_energies(emdee_md *md, double out[3]);
+int32_t emdee_md_nbr_stats(emdee_md *md, int64_t *builds, int64_t *listed, int32_t *max_count,
+                           int32_t *capacity);
+int32_t emdee_md_count_pairs(emdee_md *md, int64_t *pairs_in_cutoff);
+/* Per-kernel device time from HIP events recorded on the context's stream while
+ * profiling is on.  kernel: 0 = lj_force_nbr, 1 = verlet_kick_drift, 2 = rebuild
+ * (bin + sort + nbr_build), 3 = verlet_kick.  Blocking. */
+int32_t emdee_md_profile(emdee_md *md, int32_t enable);
+int32_t emdee_md_kernel_time(emdee_md *md, int32_t kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMDEE_HIP_H */

@@ -1,0 +1,95 @@
+"""CPU-side checks (no GPU compute): the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a device, and the host-side mirror of the reference API behaves like
+src/lennard_jones.jl / src/nonbonded.jl."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from .conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "emdee_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(emdee_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(emdee):
+    names = header_functions()
+    assert len(names) >= 40
+    lib = C.CDLL(emdee._lib.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), "libemdee_hip.so lacks %s" % name
+        assert name in emdee._lib.SIGNATURES, "python binding lacks %s" % name
+    assert sorted(emdee._lib.SIGNATURES) == names
+    assert emdee._lib.load().emdee_version() == 100
+
+
+def test_struct_layouts_match_the_julia_isbits_structs(emdee):
+    """LJAtom is 2 x Float32 (src/lennard_jones.jl:15-18); the model is 3 reals (:6-9)."""
+    assert C.sizeof(emdee._lib.LJAtomC) == 8 and emdee.LJAtom.itemsize == 8
+    assert C.sizeof(emdee._lib.LJModelC) == 24
+
+
+def test_no_device_fails_loudly(emdee):
+    if emdee.gpu_available():
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    status = emdee._lib.load().emdee_ctx_create(0, None, C.byref(h))
+    assert status == -3 and "no CPU path" in emdee._lib.last_error()
+    with pytest.raises(emdee.EmDeeError):
+        emdee.context_for()
+
+
+def test_null_arguments_are_reported_not_crashed(emdee):
+    lib = emdee._lib.load()
+    assert lib.emdee_sync(None) == -1 and "NULL" in emdee._lib.last_error()
+    assert lib.emdee_cells_update(None, None) == -1
+    assert lib.emdee_md_step(None, 1, 0.005, 0) == -1
+    assert lib.emdee_nbr_destroy(None) == 0 and lib.emdee_ctx_destroy(None) == 0
+
+
+def test_lennard_jones_model_and_atom(emdee, oracle):
+    m = emdee.LennardJonesModel(3, 2.5)                               # test/runtests.jl:24,58
+    assert (m.rc2, m.rs2) == (9.0, 6.25) and m.inv_delta2 == 1.0 / 2.75
+    om = oracle.model(3, 2.5)
+    assert (om.rc2, om.rs2, om.inv_delta2) == (m.rc2, m.rs2, m.inv_delta2)
+    with pytest.raises(ValueError):
+        emdee.LennardJonesModel(2.5, 2.5)                             # Q10: the reference builds 1/0 here
+    a = emdee.LennardJonesAtom(0.5, 0.88)
+    assert a["half_sigma"] == np.float32(0.44) and a["twice_sqrt_eps"] == np.float32(2.0 * np.sqrt(0.5))
+    arr = emdee.lennard_jones_atoms([1.0, 0.5], [1.0, 0.88])
+    oa = oracle.lj_atoms([1.0, 0.5], [1.0, 0.88])
+    assert arr.tobytes() == oa.tobytes()
+    filled = np.full(4, emdee.LennardJonesAtom(1, 1))                 # fill(LennardJonesAtom(1, 1), N)
+    assert filled.dtype == emdee.LJAtom and filled["twice_sqrt_eps"].tolist() == [2.0] * 4
+
+
+def test_bitmask_constants_and_tiles(emdee):
+    assert (emdee.FORCES, emdee.ENERGIES, emdee.VIRIALS) == (1, 2, 4)  # src/nonbonded.jl:12-14
+    assert emdee.Val(emdee.FORCES | emdee.VIRIALS).value == 5
+    t = emdee.nonbonded_computation_tiles(800)
+    assert t.N == 800 and len(t) == 13 * 14 // 2                       # n(n+1)/2 tile pairs, n = cld(N, 64)
+    assert isinstance(emdee.nonbonded_computation_tiles(800, all_pairs=True), emdee.AllPairsTiles)
+
+
+def test_synthetic_boxes(emdee_synthetic):
+    syn = emdee_synthetic
+    assert syn.fcc_box(6)[0] == 864 and syn.fcc_box(63)[0] == 1000188 and syn.fcc_box(136)[0] == 10061824
+    pos, L = syn.fcc_positions(4)
+    N = pos.shape[0]
+    assert N / L ** 3 == pytest.approx(0.8, rel=1e-12)
+    pos2, _ = syn.fcc_positions(4, chunk=100)                          # chunking does not change the stream
+    assert (pos == pos2).all()
+    u = syn.uniform(syn.SEED, np.arange(100000))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    v = syn.velocities(N)
+    assert np.abs(v.sum(axis=0)).max() < 1e-10 and np.sum(v * v) / (3 * N - 3) == pytest.approx(1.0, rel=1e-12)
+    t = syn.mixture_types(100000)
+    assert abs(t.mean() - 0.5) < 0.01
+    # splitmix64 reference vector (first outputs of the generator seeded with 0)
+    got = syn.splitmix64(np.array([0], dtype=np.uint64))[0]
+    assert int(got) == 0xE220A8397B1DCDAF

@@ -1,0 +1,384 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances: fp64 <= 1e-6 relative (north-star; observed ~1e-13); fp32 <= 1e-4 absolute on the
+reference fixture (the reference's own bound, test/runtests.jl:39-41).  Integer outputs (cell ids,
+populations, neighbour sets) are bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+REL64 = 1e-6
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def dev(emdee):
+    assert emdee.gpu_available(), "GPU tests need a MI355X"
+    return torch.device("cuda", 0)
+
+
+def zeros(dev, dtype, N):
+    t = torch.float32 if dtype == np.float32 else torch.float64
+    return (torch.zeros((N, 3), dtype=t, device=dev), torch.zeros(N, dtype=t, device=dev),
+            torch.zeros(N, dtype=t, device=dev))
+
+
+# ------------------------------------------------------------------------- the reference's own test
+def test_compute_nonbonded_reference_test(emdee, dev, lj_sample):
+    """test_compute_nonbonded(lj_sample.xyz, 10, 3, 2.5) of test/runtests.jl:19-42,58, restated:
+    Float32, all atoms LennardJonesAtom(1, 1), naive all-pairs vs the tile operator, bound 1e-4."""
+    E = emdee
+    xyz_data = lj_sample                                        # Chemfiles.positions -> CUDA.cu => Float32
+    positions = E.cu(xyz_data, dev)
+    N = xyz_data.shape[0]
+    model = E.LennardJonesModel(3, 2.5)
+    atoms = E.cu(np.full(N, E.LennardJonesAtom(1, 1)), dev)
+
+    forces_ref, energies_ref, virials_ref = zeros(dev, np.float32, N)
+    E.naively_compute_nonbonded_(forces_ref, energies_ref, virials_ref, positions, 10, model, atoms)
+
+    tiles = E.nonbonded_computation_tiles(N, all_pairs=True)    # the reference's all-pairs tile semantics
+    forces, energies, virials = zeros(dev, np.float32, N)
+    E.compute_nonbonded_(forces, energies, virials, positions, 10, tiles, model, atoms,
+                         E.Val(E.FORCES | E.ENERGIES | E.VIRIALS))
+
+    assert (forces - forces_ref).abs().max().item() < 1.0e-4     # abs, stricter than the signed maximum (Q4)
+    assert (energies - energies_ref).abs().max().item() < 1.0e-4
+    assert (virials - virials_ref).abs().max().item() < 1.0e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("mode", ["literal", "cutoff"])
+def test_all_pairs_kernels_against_oracle(emdee, oracle, dev, lj_sample, golden, dtype, mode):
+    """Tile and naive kernels vs the oracle's restatement of src/nonbonded.jl:122-155 and the numpy fixture."""
+    E = emdee
+    N = 800
+    x = lj_sample.astype(dtype)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(3.0, 2.5)
+    md = E.LITERAL if mode == "literal" else E.CUTOFF
+    f0, e0, w0 = oracle.naive(x, 10.0, oracle.model(3.0, 2.5, dtype), atoms, oracle.LITERAL if mode == "literal" else oracle.CUTOFF)
+    xd, ad = E.cu(x, dev), E.cu(atoms, dev)
+    g = golden["lj_sample_expected"]
+    for which in ("tiles", "naive"):
+        f, e, w = zeros(dev, dtype, N)
+        if which == "tiles":
+            E.compute_nonbonded_(f, e, w, xd, 10.0, E.nonbonded_computation_tiles(N, all_pairs=True, mode=md), model, ad, 7)
+        else:
+            E.naively_compute_nonbonded_(f, e, w, xd, 10.0, model, ad, mode=md)
+        f, e, w = (t.cpu().numpy() for t in (f, e, w))
+        if dtype == np.float64:
+            assert rel_err(f, f0) < REL64 and rel_err(e, e0) < REL64 and rel_err(w, w0) < REL64
+            assert rel_err(f, g["forces_" + mode]) < REL64 and rel_err(e, g["energies_" + mode]) < REL64
+            assert rel_err(w, g["virials_" + mode]) < REL64
+        else:
+            assert np.abs(f - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
+            assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 2e-4
+
+
+# ------------------------------------------------------------------------- device pair function
+def test_interaction_device_against_exact_kats(emdee, dev):
+    E = emdee
+    with open(os.path.join(GOLDEN, "kat_interaction.json")) as fh:
+        rows = json.load(fh)["rows"]
+    for row in rows:
+        model = E.LennardJonesModel(row["rc"], row["rs"])
+        assert model.rc2 == row["rc2"] and model.rs2 == row["rs2"] and model.inv_delta2 == row["inv_delta2"]
+        ai = np.array((row["half_sigma_i"], row["twice_sqrt_eps_i"]), dtype=E.LJAtom)
+        aj = np.array((row["half_sigma_j"], row["twice_sqrt_eps_j"]), dtype=E.LJAtom)
+        r2 = torch.tensor([row["r2"]], dtype=torch.float64, device=dev)
+        Ev, Wv = E.interaction(r2, model, ai, aj)
+        scale = max(abs(row["E"]), abs(row["W"]))
+        assert abs(Ev.item() - row["E"]) <= 1e-12 * scale + 1e-15, row
+        assert abs(Wv.item() - row["W"]) <= 1e-12 * scale + 1e-13, row
+        Ec, Wc = E.interaction(r2, model, ai, aj, mode=E.CUTOFF)
+        if row["beyond_cutoff"]:
+            assert Ec.item() == 0.0 and Wc.item() == 0.0
+        else:
+            assert Ec.item() == Ev.item() and Wc.item() == Wv.item()
+        E32, W32 = E.interaction(r2.float(), model, ai, aj)
+        assert abs(E32.item() - row["E"]) <= 2e-4 * scale + 1e-7
+        assert abs(W32.item() - row["W"]) <= 2e-4 * scale + 1e-6
+
+
+# ------------------------------------------------------------------------- O(N) neighbour-list path
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_neighbor_path_on_reference_fixture(emdee, oracle, dev, lj_sample, golden, dtype):
+    """compute_nonbonded_ through cell list + neighbour list + lj_force_nbr vs oracle and numpy fixture."""
+    E = emdee
+    N = 800
+    x = lj_sample.astype(dtype)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(3.0, 2.5)
+    f0, e0, w0 = oracle.nonbonded_cells(x.astype(np.float64), 10.0, oracle.model(3.0, 2.5), atoms)
+    tiles = E.nonbonded_computation_tiles(N)
+    f, e, w = zeros(dev, dtype, N)
+    E.compute_nonbonded_(f, e, w, E.cu(x, dev), 10.0, tiles, model, E.cu(atoms, dev), E.Val(7))
+    f, e, w = (t.cpu().numpy() for t in (f, e, w))
+    g = golden["lj_sample_expected"]
+    if dtype == np.float64:
+        assert rel_err(f, f0) < REL64 and rel_err(e, e0) < REL64 and rel_err(w, w0) < REL64
+        assert rel_err(f, g["forces_cutoff"]) < REL64 and rel_err(e, g["energies_cutoff"]) < REL64
+        assert e.sum() == pytest.approx(-4292.184050996729, rel=1e-10)
+        assert w.sum() == pytest.approx(-957.3125855282784, rel=1e-10)
+        assert np.abs(f.sum(axis=0)).max() < 1e-9
+    else:
+        assert np.abs(f - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
+        assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 2e-4
+    st = tiles.stats()
+    assert st["builds"] == 1 and st["max_count"] <= st["capacity"]
+    off, nb = oracle.neighbor_list(x.astype(np.float64), 10.0, 3.0 + 0.3)
+    if dtype == np.float64:
+        assert st["listed"] == off[-1]                                          # same neighbour set as the oracle
+        assert tiles.count_pairs() == 35677                                     # pairs with r < 3
+
+
+def test_bitmask_selects_outputs(emdee, oracle, dev, lj_sample):
+    """Val(bitmask): only selected outputs are written (src/nonbonded.jl:112-114,88-104)."""
+    E = emdee
+    N = 800
+    x = lj_sample.astype(np.float64)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(3.0, 2.5)
+    f0, e0, w0 = oracle.nonbonded_cells(x, 10.0, oracle.model(3.0, 2.5), atoms)
+    xd, ad = E.cu(x, dev), E.cu(atoms, dev)
+    for tiles in (E.nonbonded_computation_tiles(N), E.nonbonded_computation_tiles(N, all_pairs=True, mode=E.CUTOFF)):
+        for mask in range(1, 8):
+            f, e, w = zeros(dev, np.float64, N)
+            f.fill_(7.0); e.fill_(7.0); w.fill_(7.0)
+            E.compute_nonbonded_(f, e, w, xd, 10.0, tiles, model, ad, E.Val(mask))
+            f, e, w = (t.cpu().numpy() for t in (f, e, w))
+            assert (rel_err(f, f0) < REL64) if mask & E.FORCES else (f == 7.0).all()
+            assert (rel_err(e, e0) < REL64) if mask & E.ENERGIES else (e == 7.0).all()
+            assert (rel_err(w, w0) < REL64) if mask & E.VIRIALS else (w == 7.0).all()
+    # unselected outputs may be None
+    f, _, _ = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f, None, None, xd, 10.0, E.nonbonded_computation_tiles(N), model, ad, E.FORCES)
+    assert rel_err(f.cpu().numpy(), f0) < REL64
+
+
+@pytest.mark.parametrize("N", [0, 1, 2, 31, 33, 63, 65, 130, 799])
+def test_ragged_sizes(emdee, oracle, dev, lj_sample, N):
+    """Any N: the reference only works for N % 32 == 0."""
+    E = emdee
+    x = lj_sample[:N].astype(np.float64)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(3.0, 2.5)
+    f0, e0, w0 = oracle.naive(x, 10.0, oracle.model(3.0, 2.5), atoms, oracle.CUTOFF)
+    xd, ad = E.cu(x.reshape(N, 3), dev), E.cu(atoms, dev)
+    for tiles in (E.nonbonded_computation_tiles(N), E.nonbonded_computation_tiles(N, all_pairs=True, mode=E.CUTOFF)):
+        f, e, w = zeros(dev, np.float64, N)
+        E.compute_nonbonded_(f, e, w, xd, 10.0, tiles, model, ad, 7)
+        if N:
+            assert np.abs(f.cpu().numpy() - f0).max() <= REL64 * max(np.abs(f0).max(), 1.0)
+            assert np.abs(e.cpu().numpy() - e0).max() <= REL64 * max(np.abs(e0).max(), 1.0)
+    if N:
+        f, e, w = zeros(dev, np.float64, N)
+        E.naively_compute_nonbonded_(f, e, w, xd, 10.0, model, ad, mode=E.CUTOFF)
+        assert np.abs(f.cpu().numpy() - f0).max() <= REL64 * max(np.abs(f0).max(), 1.0)
+
+
+def test_fcc864_and_binary_mixture(emdee, oracle, dev, golden):
+    """BASELINE configs[0] box and the two-species box (Lorentz-Berthelot through LJAtom)."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(6)
+    g = golden["fcc864_expected"]
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 864)
+    f, e, w = zeros(dev, np.float64, 864)
+    E.compute_nonbonded_(f, e, w, E.cu(pos, dev), L, E.nonbonded_computation_tiles(864), E.LennardJonesModel(2.5, 2.0),
+                         E.cu(atoms, dev), 7)
+    assert rel_err(f.cpu().numpy(), g["forces"]) < REL64 and rel_err(e.cpu().numpy(), g["energies"]) < REL64
+    assert rel_err(w.cpu().numpy(), g["virials"]) < REL64
+    gm = golden["mix500_expected"]
+    pos, L = syn.fcc_positions(5)
+    eps, sigma = syn.mixture_parameters(syn.mixture_types(500))
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    for dtype, tol in ((np.float64, REL64), (np.float32, 2e-4)):
+        f, e, w = zeros(dev, dtype, 500)
+        E.compute_nonbonded_(f, e, w, E.cu(pos.astype(dtype), dev), L, E.nonbonded_computation_tiles(500),
+                             E.LennardJonesModel(3.5, 3.0), E.cu(atoms, dev), 7)
+        assert rel_err(f.cpu().numpy(), gm["forces"]) < tol and rel_err(e.cpu().numpy(), gm["energies"]) < tol
+
+
+def test_list_reuse_and_rebuild_trigger(emdee, oracle, dev):
+    """Small moves reuse the list (skin), large moves rebuild it; results always match the oracle."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(8)                                  # 2048 atoms
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model, om = E.LennardJonesModel(2.5, 2.0), oracle.model(2.5, 2.0)
+    tiles = E.nonbonded_computation_tiles(N, skin=0.3)
+    ad = E.cu(atoms, dev)
+    rng = np.random.default_rng(3)
+    x = pos.copy()
+    expected_builds = 0
+    for k, amp in enumerate((0.0, 0.05, 0.05, 0.5, 0.01)):
+        step = rng.uniform(-1, 1, size=x.shape)
+        step /= np.linalg.norm(step, axis=1, keepdims=True)
+        x = x + amp * step
+        if k == 4:
+            x = x + np.array([L, -2 * L, 3 * L])                    # whole-box translations are invisible
+        f, e, w = zeros(dev, np.float64, N)
+        E.compute_nonbonded_(f, e, w, E.cu(x, dev), L, tiles, model, ad, 7)
+        f0, e0, w0 = oracle.nonbonded_cells(x, L, om, atoms)
+        assert rel_err(f.cpu().numpy(), f0) < REL64 and rel_err(e.cpu().numpy(), e0) < REL64
+        expected_builds += 1 if k in (0, 3) else 0                  # 0.05 + 0.05 < skin/2 = 0.15 < 0.5
+        assert tiles.stats()["builds"] == expected_builds
+
+
+def test_medium_box_against_oracle_cells(emdee, oracle, dev):
+    """32,000 atoms: many cells per dimension, periodic wrap of the stencil rows, ELL rows > 64 entries."""
+    E = emdee
+    pos, L = E.synthetic.fcc_positions(20)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(2.5, 2.0), atoms)
+    tiles = E.nonbonded_computation_tiles(N)
+    f, e, w = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f, e, w, E.cu(pos, dev), L, tiles, E.LennardJonesModel(2.5, 2.0), E.cu(atoms, dev), 7)
+    assert rel_err(f.cpu().numpy(), f0) < REL64 and rel_err(e.cpu().numpy(), e0) < REL64 and rel_err(w.cpu().numpy(), w0) < REL64
+    off, _ = oracle.neighbor_list(pos, L, 2.8)
+    assert tiles.stats()["listed"] == off[-1]
+
+
+# ------------------------------------------------------------------------- Cells
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cells_bit_exact(emdee, oracle, dev, dtype):
+    """Cells index/population are integers: bit-exact against the oracle (src/cells.jl:36,180-181)."""
+    E = emdee
+    rng = np.random.default_rng(11)
+    r = rng.uniform(-4.0, 14.0, size=(5000, 3)).astype(dtype)
+    M, index, pop = oracle.cells(r, 10.0, 2.0, ndiv=2)
+    cells = E.Cells(E.cu(r, dev), 10.0, 2.0)
+    assert cells.M == M == 10
+    np.testing.assert_array_equal(cells.index.cpu().numpy(), index)
+    np.testing.assert_array_equal(cells.population.cpu().numpy(), pop)
+    start, order = cells.start.cpu().numpy(), cells.order.cpu().numpy()
+    np.testing.assert_array_equal(start, np.concatenate([[0], np.cumsum(pop)]))
+    np.testing.assert_array_equal(order, np.argsort(index, kind="stable"))        # ascending ids inside a cell
+
+
+def test_cells_update(emdee, oracle, dev):
+    """The reference's commented-out test_cells (test/runtests.jl:6-17): update_cells! after a small
+    displacement gives the same index and population as a fresh build."""
+    E = emdee
+    N, L, cutoff = 1000, 1.0, 0.2
+    rng = np.random.default_rng(5)
+    x = rng.uniform(size=(N, 3)).astype(np.float32)
+    y = x + np.float32(0.01)
+    cells_x = E.Cells(E.cu(x, dev), L, cutoff)
+    cells_y = E.Cells(E.cu(y, dev), L, cutoff)
+    E.update_cells_(cells_x, E.cu(y, dev), L)
+    assert (cells_x.index == cells_y.index).all() and (cells_x.population == cells_y.population).all()
+    np.testing.assert_array_equal(cells_x.index.cpu().numpy(), oracle.cells(y, L, cutoff)[1])
+
+
+# ------------------------------------------------------------------------- velocity-Verlet
+def test_verlet_100_steps_config0(emdee, oracle, dev, golden):
+    """BASELINE.json configs[0]: 864-atom fcc box, rho* = 0.8, rc = 2.5, 100 steps, dt = 0.005."""
+    E = emdee
+    syn = E.synthetic
+    g = golden["fcc864_expected"]
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(864)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 864)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(2.5, 2.0), E.cu(atoms, dev))
+    ep0, ek0, _ = md.totals()
+    assert ep0 == pytest.approx(g["epot"][0], rel=1e-10) and ek0 == pytest.approx(g["ekin"][0], rel=1e-10)
+    for chunk in (1, 9, 40, 50):                                     # fused kicks across arbitrary call boundaries
+        md.step_(chunk, 0.005)
+    st = md.state(energies=True, virials=True)
+    np.testing.assert_allclose(st["positions"].cpu().numpy(), g["x100"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(st["velocities"].cpu().numpy(), g["v100"], rtol=0, atol=1e-7)
+    assert rel_err(st["forces"].cpu().numpy(), g["f100"]) < REL64
+    ep, ek, vir = md.totals()
+    assert ep == pytest.approx(g["epot"][100], rel=1e-8) and ek == pytest.approx(g["ekin"][100], rel=1e-8)
+    assert vir == pytest.approx(g["virial"][100], rel=1e-7)
+    assert abs((ep + ek) / (ep0 + ek0) - 1.0) < 1e-4                 # NVE drift bound, SURVEY 8(c)
+    assert md.nbr_stats()["builds"] >= 2                             # the displacement trigger fired
+
+
+def test_verlet_fixed_cadence_and_masses(emdee, oracle, dev):
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(864)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 864)
+    inv_mass = np.where(np.arange(864) % 2 == 0, 1.0, 0.5)
+    ref = oracle.verlet(pos, vel, L, oracle.model(2.5, 2.0), atoms, 0.004, 30, inv_mass=inv_mass)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(2.5, 2.0), E.cu(atoms, dev),
+                          inv_mass=E.cu(inv_mass, dev))
+    md.step_(30, 0.004, rebuild_every=5)
+    st = md.state()
+    np.testing.assert_allclose(st["positions"].cpu().numpy(), ref["x"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(st["velocities"].cpu().numpy(), ref["v"], rtol=0, atol=1e-8)
+    ep, ek, _ = md.totals()
+    assert ep == pytest.approx(ref["epot"][-1], rel=1e-9) and ek == pytest.approx(ref["ekin"][-1], rel=1e-9)
+    assert md.nbr_stats()["builds"] == 1 + 6
+
+
+def test_verlet_fp32_mixed_precision(emdee, oracle, dev):
+    """BASELINE config 4 arithmetic: fp32 storage and pair math, fp64 energy reduction."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(864)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 864)
+    ref = oracle.verlet(pos, vel, L, oracle.model(2.5, 2.0), atoms, 0.005, 20)
+    md = E.VelocityVerlet(E.cu(pos.astype(np.float32), dev), E.cu(vel.astype(np.float32), dev), L,
+                          E.LennardJonesModel(2.5, 2.0), E.cu(atoms, dev))
+    md.step_(20, 0.005)
+    st = md.state()
+    assert np.abs(st["positions"].cpu().numpy() - ref["x"]).max() < 5e-4
+    ep, ek, _ = md.totals()
+    assert ep == pytest.approx(ref["epot"][-1], rel=2e-5) and ek == pytest.approx(ref["ekin"][-1], rel=2e-4)
+
+
+# ------------------------------------------------------------------------- full-size properties
+def test_million_atoms_properties(emdee, oracle, dev):
+    """BASELINE configs[1] size (fcc 63^3 x 4 = 1,000,188 atoms, fp64): properties that need no oracle
+    at full size plus an oracle check on a slab of atoms."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(63)
+    N = pos.shape[0]
+    assert N == 1000188
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(2.5, 2.0)
+    tiles = E.nonbonded_computation_tiles(N)
+    xd, ad = E.cu(pos, dev), E.cu(atoms, dev)
+    f, e, w = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f, e, w, xd, L, tiles, model, ad, 7)
+    fs = f.sum(dim=0).abs().max().item()
+    assert fs < 1e-6 * f.abs().max().item() * np.sqrt(N)           # Newton's third law, full list
+    # permutation invariance: shuffled atom order gives the same per-atom results
+    perm = torch.randperm(N, device=dev)
+    f2, e2, w2 = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f2, e2, w2, xd[perm].contiguous(), L, E.nonbonded_computation_tiles(N), model, ad, 7)
+    assert (f2 - f[perm]).abs().max().item() < 1e-9 * f.abs().max().item()
+    assert (e2 - e[perm]).abs().max().item() < 1e-9 * e.abs().max().item()
+    # box-translation invariance of the periodic path
+    f3, e3, w3 = zeros(dev, np.float64, N)
+    shift = torch.tensor([L, -L, 2 * L], dtype=torch.float64, device=dev)
+    E.compute_nonbonded_(f3, e3, w3, xd + shift, L, tiles, model, ad, 7)
+    assert (f3 - f).abs().max().item() < 1e-8 * f.abs().max().item()
+    # oracle on the full box (OpenMP cell list, a few seconds)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(2.5, 2.0), atoms)
+    assert rel_err(f.cpu().numpy(), f0) < REL64 and rel_err(e.cpu().numpy(), e0) < REL64 and rel_err(w.cpu().numpy(), w0) < REL64
+    pairs = tiles.count_pairs()
+    assert abs(pairs / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 0.2      # n(rc)/2 = 26.18 pairs per atom
