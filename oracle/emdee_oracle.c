@@ -87,7 +87,7 @@ int32_t orc_cells_f64(int32_t N, const double *pos, double L, double cutoff, int
                       int32_t *index, int32_t *population)
 { return cells_f64(N, pos, L, cutoff, ndiv, index, population); }
 
-int32_t orc_cells_f32(int32_t N, const float *pos, float L, float cutoff, int32_t ndiv,
+int32_t orc_cells_f32(int32_t N, const float *pos, double L, double cutoff, int32_t ndiv,
                       int32_t *index, int32_t *population)
 { return cells_f32(N, pos, L, cutoff, ndiv, index, population); }
 

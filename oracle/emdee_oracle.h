@@ -71,7 +71,7 @@ void orc_naive_f64(int32_t N, const double *pos, double L, const orc_model64 *m,
 int32_t orc_cells_per_dimension(double L, double cutoff, int32_t ndiv);
 int32_t orc_cells_f64(int32_t N, const double *pos, double L, double cutoff, int32_t ndiv,
                       int32_t *index, int32_t *population);
-int32_t orc_cells_f32(int32_t N, const float *pos, float L, float cutoff, int32_t ndiv,
+int32_t orc_cells_f32(int32_t N, const float *pos, double L, double cutoff, int32_t ndiv,
                       int32_t *index, int32_t *population);
 
 /* Full neighbour list (both i->j and j->i) of all minimum-image pairs with

@@ -67,7 +67,7 @@ def lib():
         L.orc_cells_per_dimension.restype = C.c_int32
         L.orc_cells_f64.argtypes = [C.c_int32, p, C.c_double, C.c_double, C.c_int32, p, p]
         L.orc_cells_f64.restype = C.c_int32
-        L.orc_cells_f32.argtypes = [C.c_int32, p, C.c_float, C.c_float, C.c_int32, p, p]
+        L.orc_cells_f32.argtypes = [C.c_int32, p, C.c_double, C.c_double, C.c_int32, p, p]
         L.orc_cells_f32.restype = C.c_int32
         L.orc_neighbor_list_f64.argtypes = [C.c_int32, p, C.c_double, C.c_double, p, p]
         L.orc_neighbor_list_f64.restype = C.c_int64
