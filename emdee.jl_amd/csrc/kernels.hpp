@@ -195,24 +195,6 @@ static __global__ void k_scan_add(int *__restrict__ out, size_t n, const int *__
 }
 
 // ------------------------------------------------------------------------------------ gathers
-// Build the cell-ordered state from caller-order arrays.  order[p] = caller id of slot p.
-template <typename real>
-__global__ void k_gather_user(int n, int n_owned, size_t pitch, const int *__restrict__ order,
-                              const int *__restrict__ cell_of, const real *__restrict__ pos,
-                              const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ vel,
-                              const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
-                              real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
-                              int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted);
-
-// Re-sort an already cell-ordered state (MD rebuild). order[p] = OLD slot of new slot p.
-template <typename real>
-__global__ void k_gather_sorted(int n, size_t pitch, const int *__restrict__ order, const int *__restrict__ cell_of,
-                                const Rec<real> *__restrict__ rec_in, const float *__restrict__ te_in,
-                                const real *__restrict__ v_in, const real *__restrict__ im_in,
-                                const int *__restrict__ perm_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
-                                real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
-                                int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted);
-
 template <typename real>
 __device__ __forceinline__ void store_rec(Rec<real> *rec, float *te, int p, real x, real y, real z, float hs, float tev);
 template <>
@@ -237,17 +219,42 @@ __device__ __forceinline__ void rec_params(const Rec<float> *rec, const float *t
     hs = rec[p].hs; tev = te[p];
 }
 
+// Cell-ordered records hold the image of each atom INSIDE the primary box along periodic
+// dimensions (the LDS-tiled kernels add explicit +-L shifts and never apply a minimum image);
+// the number of box lengths removed is kept per atom so caller-order copies return the
+// caller's unwrapped coordinates.  Packed 3 x 10 bits, biased by 512.
+constexpr int IMG_BIAS = 512;
+__device__ __forceinline__ int img_pack(int kx, int ky, int kz) {
+    return (kx + IMG_BIAS) | ((ky + IMG_BIAS) << 10) | ((kz + IMG_BIAS) << 20);
+}
+__device__ __forceinline__ void img_unpack(int v, int &kx, int &ky, int &kz) {
+    kx = (v & 1023) - IMG_BIAS; ky = ((v >> 10) & 1023) - IMG_BIAS; kz = ((v >> 20) & 1023) - IMG_BIAS;
+}
 template <typename real>
-__global__ void k_gather_user(int n, int n_owned, size_t pitch, const int *__restrict__ order,
+__device__ __forceinline__ int wrap_into_box(real &p, real lo, real len, int periodic) {
+    if (!periodic) return 0;
+    const real k = floor((p - lo) / len);
+    p -= k * len;
+    return (int)k;
+}
+
+// Build the cell-ordered state from caller-order arrays.  order[p] = caller id of slot p.
+template <typename real>
+__global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, const int *__restrict__ order,
                               const int *__restrict__ cell_of, const real *__restrict__ pos,
                               const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ vel,
                               const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
                               real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
-                              int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted) {
+                              int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
+                              int *__restrict__ img) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int i = order[p];
     real x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    const int kx = wrap_into_box(x, g.lo[0], g.len[0], g.per[0]);
+    const int ky = wrap_into_box(y, g.lo[1], g.len[1], g.per[1]);
+    const int kz = wrap_into_box(z, g.lo[2], g.len[2], g.per[2]);
+    img[p] = img_pack(kx, ky, kz);
     emdee_lj_atom a = atoms[i];
     store_rec<real>(rec, te, p, x, y, z, a.half_sigma, a.twice_sqrt_eps);
     xb[p] = x; xb[pitch + p] = y; xb[2 * pitch + p] = z;
@@ -261,19 +268,28 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, const int *__res
     cell_sorted[p] = cell_of[i];
 }
 
+// Re-sort an already cell-ordered state (MD rebuild). order[p] = OLD slot of new slot p.
 template <typename real>
-__global__ void k_gather_sorted(int n, size_t pitch, const int *__restrict__ order, const int *__restrict__ cell_of,
-                                const Rec<real> *__restrict__ rec_in, const float *__restrict__ te_in,
-                                const real *__restrict__ v_in, const real *__restrict__ im_in,
-                                const int *__restrict__ perm_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
+__global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *__restrict__ order,
+                                const int *__restrict__ cell_of, const Rec<real> *__restrict__ rec_in,
+                                const float *__restrict__ te_in, const real *__restrict__ v_in,
+                                const real *__restrict__ im_in, const int *__restrict__ perm_in,
+                                const int *__restrict__ img_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
                                 real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
-                                int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted) {
+                                int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
+                                int *__restrict__ img) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int o = order[p];
     Rec<real> r = rec_in[o];
     float hs, tev;
     rec_params(rec_in, te_in, o, hs, tev);
+    int kx, ky, kz;
+    img_unpack(img_in[o], kx, ky, kz);
+    kx += wrap_into_box(r.x, g.lo[0], g.len[0], g.per[0]);
+    ky += wrap_into_box(r.y, g.lo[1], g.len[1], g.per[1]);
+    kz += wrap_into_box(r.z, g.lo[2], g.len[2], g.per[2]);
+    img[p] = img_pack(kx, ky, kz);
     store_rec<real>(rec, te, p, r.x, r.y, r.z, hs, tev);
     xb[p] = r.x; xb[pitch + p] = r.y; xb[2 * pitch + p] = r.z;
     if (v_out) {
@@ -286,17 +302,21 @@ __global__ void k_gather_sorted(int n, size_t pitch, const int *__restrict__ ord
     cell_sorted[p] = cell_of[o];
 }
 
-// Operator path: same list, new caller positions -> refresh the records in place.
+// Operator path: same list, new caller positions -> refresh the records in place, each atom in the
+// periodic image nearest to where it was at build time (the caller may have wrapped or shifted it).
 template <typename real>
-__global__ void k_refresh_positions(int n, const int *__restrict__ perm, const real *__restrict__ pos,
-                                    const emdee_lj_atom *__restrict__ atoms, Rec<real> *__restrict__ rec,
-                                    float *__restrict__ te) {
+__global__ void k_refresh_positions(int n, size_t pitch, GridP<real> g, const int *__restrict__ perm,
+                                    const real *__restrict__ pos, const emdee_lj_atom *__restrict__ atoms,
+                                    const real *__restrict__ xb, Rec<real> *__restrict__ rec, float *__restrict__ te) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int i = perm[p];
     emdee_lj_atom a = atoms[i];
-    store_rec<real>(rec, te, p, pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], a.half_sigma,
-                    a.twice_sqrt_eps);
+    const real bx = xb[p], by = xb[pitch + p], bz = xb[2 * pitch + p];
+    const real x = bx + min_image(pos[3 * (size_t)i] - bx, g.plen[0], g.pinv[0]);
+    const real y = by + min_image(pos[3 * (size_t)i + 1] - by, g.plen[1], g.pinv[1]);
+    const real z = bz + min_image(pos[3 * (size_t)i + 2] - bz, g.plen[2], g.pinv[2]);
+    store_rec<real>(rec, te, p, x, y, z, a.half_sigma, a.twice_sqrt_eps);
 }
 
 // Operator path: has any atom moved more than sqrt(thr2) (minimum image) since the build?
@@ -516,7 +536,8 @@ __global__ void k_kick(int n, int n_owned, size_t pitch, const int *__restrict__
 
 // ------------------------------------------------------------------------------------ caller-order copies
 template <typename real>
-__global__ void k_unsort(int n_owned, int n_total, size_t pitch, const int *__restrict__ inv_perm,
+__global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, const int *__restrict__ img,
+                         const int *__restrict__ inv_perm,
                          const Rec<real> *__restrict__ rec, const real *__restrict__ vel, const real *__restrict__ frc,
                          const real *__restrict__ en, const real *__restrict__ vir, real *__restrict__ pos_out,
                          real *__restrict__ vel_out, real *__restrict__ frc_out, real *__restrict__ en_out,
@@ -526,7 +547,11 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, const int *__re
     int p = inv_perm[i];
     if (pos_out) {
         Rec<real> r = rec[p];
-        pos_out[3 * (size_t)i] = r.x; pos_out[3 * (size_t)i + 1] = r.y; pos_out[3 * (size_t)i + 2] = r.z;
+        int kx, ky, kz;
+        img_unpack(img[p], kx, ky, kz);   // back to the caller's (unwrapped) image
+        pos_out[3 * (size_t)i] = r.x + (real)kx * g.len[0];
+        pos_out[3 * (size_t)i + 1] = r.y + (real)ky * g.len[1];
+        pos_out[3 * (size_t)i + 2] = r.z + (real)kz * g.len[2];
     }
     if (i >= n_owned) return;
     if (vel_out) for (int d = 0; d < 3; d++) vel_out[3 * (size_t)i + d] = vel[d * pitch + p];

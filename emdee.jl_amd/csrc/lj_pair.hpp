@@ -1,23 +1,33 @@
 // lj_pair.hpp -- the device pair function.
-// Follows interaction(r2, model, atom_i, atom_j) of the reference, src/lennard_jones.jl:25-42,
-// term by term; the only algebraic change is one reciprocal of r2 shared by s^-2 = sigma^2/r2
-// (:31) and by the caller's W/r2 (src/nonbonded.jl:74,139).
+// Restates interaction(r2, model, atom_i, atom_j) of the reference, src/lennard_jones.jl:25-42.
+// Same function, fewer fp64 instructions (this kernel is fp64-issue bound on gfx950, 4 cycles per
+// wave64 instruction): one reciprocal of r2 shared by s^-2 = sigma^2/r2 (:31) and by the caller's
+// W/r2 (src/nonbonded.jl:74,139); E and W/6 from one product t = 4 eps s^-12 (E = t - 4 eps s^-6,
+// W/6 = E + t); the switch polynomials in Horner/product form.  Differences from the literal
+// operation order are a few ulp.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 namespace emdee {
 
-// LennardJonesModel, src/lennard_jones.jl:6-11, in the kernel's real type
+// LennardJonesModel, src/lennard_jones.jl:6-11, in the kernel's real type, plus constants derived
+// once on the host: x = r2 idl2 - rs2 idl2 ;  -r g' = 60 idl2 x^2 (1-x)^2 r2
 template <typename real>
 struct LJModel {
     real rc2, rs2, idl2;
+    real x0;      // rs2 * idl2
+    real c60;     // 60 * idl2
 };
 
 template <typename real>
 static inline LJModel<real> make_model(const emdee_lj_model &m) {
     // EMDEE_F32: round each field to float = the reference's Float32 struct
-    return LJModel<real>{(real)m.rc2, (real)m.rs2, (real)m.inv_delta2};
+    LJModel<real> r;
+    r.rc2 = (real)m.rc2; r.rs2 = (real)m.rs2; r.idl2 = (real)m.inv_delta2;
+    r.x0 = r.rs2 * r.idl2;
+    r.c60 = (real)60 * r.idl2;
+    return r;
 }
 
 __device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }   // v_rcp_f32, 1 ulp
@@ -29,29 +39,34 @@ __device__ __forceinline__ double fast_rcp(double a) {
     return r;
 }
 
-// The reference clamp  x *= 0.5 (sign(x) - sign(x-1))  (src/lennard_jones.jl:37) as selects:
-// 0 < x < 1 -> x ;  x == 1 -> 0.5 (Q2) ;  otherwise 0 (including x > 1: g = 1 beyond rc, Q1).
+// The reference clamp  x *= 0.5 (sign(x) - sign(x-1))  (src/lennard_jones.jl:37):
+// 0 < x < 1 -> x ;  x <= 0 -> 0 ;  x == 1 -> 0.5 (Q2) ;  x > 1 -> 0 (g = 1 beyond rc, Q1).
+// One max covers the common cases; x >= 1 is a rare, separately handled lane state.
 template <typename real>
 __device__ __forceinline__ real switch_clamp(real x) {
-    real inside = (x > (real)0 && x < (real)1) ? x : (real)0;
-    return (x == (real)1) ? (real)0.5 : inside;
+    x = x > (real)0 ? x : (real)0;
+    if (__builtin_expect(x >= (real)1, 0)) x = (x == (real)1) ? (real)0.5 : (real)0;
+    return x;
 }
 
 // Returns (E g, W g + E (-r g')) given r2 and inv_r2 = 1/r2.  CUTOFF semantics (r2 >= rc2
-// contributes nothing) are the CALLER's test; this is the literal formula.
+// contributes nothing) are the CALLER's test; this is the literal function.
 template <typename real>
 __device__ __forceinline__ void lj_interaction(real r2, real inv_r2, const LJModel<real> &m, real hs_i, real te_i,
                                                real hs_j, real te_j, real &E_out, real &W_out) {
-    real sigma = hs_i + hs_j;                                          // :29
-    real s2 = sigma * sigma * inv_r2;                                  // :31
-    real s6 = s2 * s2 * s2;                                            // :32
-    real e4s6 = te_i * te_j * s6;                                      // :33
-    real E = e4s6 * (s6 - (real)1);                                    // :34
-    real W = (real)6 * e4s6 * ((real)2 * s6 - (real)1);                // :35
-    real x = switch_clamp((r2 - m.rs2) * m.idl2);                      // :36-37
-    real x2 = x * x;                                                   // :38
-    real g = (real)1 + x * x2 * ((real)15 * x - (real)6 * x2 - (real)10);            // :39
-    real mgr = (real)60 * x2 * ((real)1 - (real)2 * x + x2) * m.idl2 * r2;            // :40
+    const real sigma = hs_i + hs_j;                                    // :29
+    const real s2 = sigma * sigma * inv_r2;                            // :31
+    const real s6 = s2 * s2 * s2;                                      // :32
+    const real e4s6 = te_i * te_j * s6;                                // :33  4 eps s^-6
+    const real t = e4s6 * s6;                                          //      4 eps s^-12
+    const real E = t - e4s6;                                           // :34  4 eps (s^-12 - s^-6)
+    const real W = (real)6 * (E + t);                                  // :35  24 eps (2 s^-12 - s^-6)
+    const real x = switch_clamp(r2 * m.idl2 - m.x0);                   // :36-37
+    const real x2 = x * x;                                             // :38
+    const real q = (real)15 * x - (real)10 - (real)6 * x2;             // :39  g = 1 + x^3 (15 x - 6 x^2 - 10)
+    const real g = (real)1 + x2 * x * q;
+    const real u = (real)1 - x;                                        // :40  1 - 2x + x^2 = (1-x)^2
+    const real mgr = m.c60 * (x2 * (u * u)) * r2;                      //      -r g' = 60 x^2 (1-x)^2 idl2 r2
     E_out = E * g;                                                     // :41
     W_out = W * g + E * mgr;
 }

@@ -1,15 +1,19 @@
 // nbsys.hpp -- host-side driver of the cell-ordered system: owns the HBM buffers and enqueues
-// the kernels of kernels.hpp on the context's stream.  Instantiated for float and double.
+// the kernels of kernels.hpp / brick.hpp on the context's stream.  Instantiated for float and double.
 #pragma once
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
+#include "brick.hpp"
 #include "kernels.hpp"
 
 namespace emdee {
 
 enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_COUNT = 4 };
+enum PathId { PATH_BRICK = 0, PATH_DIRECT = 1 };
 
 // in-place exclusive scan of int32 data[0..n) (n may exceed one tile: recursive tile sums)
 struct Scanner {
@@ -38,13 +42,48 @@ struct Scanner {
     }
 };
 
+// ---- brick kernel variants (shape, workgroup size, lanes per atom); variant 0 is the default ----
+constexpr int BRICK_VARIANTS = 8;
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <int V>
+struct BrickVariant;
+template <> struct BrickVariant<0> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 8; };
+template <> struct BrickVariant<1> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 256, G = 16; };
+template <> struct BrickVariant<2> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 16; };
+template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 16; };
+template <> struct BrickVariant<4> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 32; };
+template <> struct BrickVariant<5> { using Shape = BrickShape<8, 2, 2>; static constexpr int THREADS = 512, G = 16; };
+template <> struct BrickVariant<6> { using Shape = BrickShape<4, 4, 2>; static constexpr int THREADS = 512, G = 16; };
+template <> struct BrickVariant<7> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
+
+template <class F>
+static inline void with_brick_variant(int v, F &&f) {
+    switch (v) {
+        case 1: f(BrickVariant<1>{}); break;
+        case 2: f(BrickVariant<2>{}); break;
+        case 3: f(BrickVariant<3>{}); break;
+        case 4: f(BrickVariant<4>{}); break;
+        case 5: f(BrickVariant<5>{}); break;
+        case 6: f(BrickVariant<6>{}); break;
+        case 7: f(BrickVariant<7>{}); break;
+        default: f(BrickVariant<0>{}); break;
+    }
+}
+
+template <typename K>
+static inline void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        EMDEE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
 template <typename real>
 struct NbSystem {
     emdee_ctx *ctx = nullptr;
     double lo[3] = {0, 0, 0}, len[3] = {0, 0, 0};
     int per[3] = {1, 1, 1};
     double skin = 0.3, rlist = 0.0;
-    int ndiv = 1;
     emdee_lj_model model_d{};
     LJModel<real> model{};
     GridP<real> grid{};
@@ -58,13 +97,26 @@ struct NbSystem {
     bool profiling = false;
     KernelTimer timers[T_COUNT];
 
+    // path selection
+    int path = PATH_BRICK;
+    int variant = 0;
+    BrickGrid bgrid{};
+    int tile_cap = 0, own_cap = 0, row_block = 1;
+    size_t lds_bytes = 0;
+
     DevBuf<Rec<real>> rec, rec2;
     DevBuf<float> te, te2;
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb;
-    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags;
+    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags, img, img2;
+    DevBuf<unsigned short> nbr16;
     DevBuf<double> partial, sums;
     DevBuf<unsigned long long> stats;
     Scanner scanner;
+
+    NbSystem() {
+        if (const char *e = std::getenv("EMDEE_PATH")) path = (std::string(e) == "direct") ? PATH_DIRECT : PATH_BRICK;
+        if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
+    }
 
     hipStream_t stream() const { return ctx->stream; }
     AtomView<real> view() const { return AtomView<real>{rec.ptr, te.ptr}; }
@@ -111,7 +163,7 @@ struct NbSystem {
             if (per[d])
                 EMDEE_REQUIRE(rlist <= 0.5 * len[d], EMDEE_ERR_INVALID,
                               "cutoff + skin = %g exceeds half the periodic box length %g (minimum image)", rlist, len[d]);
-            M[d] = std::max(1, (int)std::floor(len[d] * ndiv / rlist));
+            M[d] = std::max(1, (int)std::floor(len[d] / rlist));   // cell side >= rlist: 27-cell stencil
             M[d] = std::min(M[d], 1024);
         }
         // sparse boxes: never more cells than ~4 per atom (larger cells stay valid)
@@ -130,7 +182,7 @@ struct NbSystem {
             g.M[d] = M[d];
             cells *= (size_t)M[d];
         }
-        g.nd = ndiv;
+        g.nd = 1;
         g.one_based = 0;
         grid = g;
         ncell = cells;
@@ -146,7 +198,7 @@ struct NbSystem {
         frc.ensure(3 * pitch); en.ensure(pitch); vir.ensure(pitch); xb.ensure(3 * pitch);
         if (velocities) { vel.ensure(3 * pitch); vel2.ensure(3 * pitch); }
         if (masses) { im.ensure(pitch); im2.ensure(pitch); }
-        perm.ensure(n + 1); perm2.ensure(n + 1); inv_perm.ensure(n + 1);
+        perm.ensure(n + 1); perm2.ensure(n + 1); inv_perm.ensure(n + 1); img.ensure(n + 1); img2.ensure(n + 1);
         cell_of.ensure(n + 1); cell_sorted.ensure(n + 1); order.ensure(n + 1); tmp.ensure(n + 1); cnt.ensure(n + 1);
         if (flags.ensure(16)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 16 * sizeof(int), stream()));
         partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
@@ -184,9 +236,9 @@ struct NbSystem {
         bin(UserPos<real>{pos}, nullptr);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
-                               order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
+                               grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
-                               cell_sorted.ptr);
+                               cell_sorted.ptr, img.ptr);
         sorted = true;
         build_list();
     }
@@ -199,18 +251,84 @@ struct NbSystem {
         configure_grid();
         bin(RecPos<real>{rec.ptr}, perm.ptr);
         if (n > 0)
-            hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch,
+            hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
-                               with_mass ? im.ptr : nullptr, perm.ptr, rec2.ptr, te2.ptr, xb.ptr,
+                               with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr);
-        rec.swap(rec2); te.swap(te2); perm.swap(perm2);
+                               cell_sorted.ptr, img2.ptr);
+        rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2);
         if (with_vel) vel.swap(vel2);
         if (with_mass) im.swap(im2);
         build_list();
     }
 
+    // ---------------------------------------------------------------- brick plumbing
+    BrickArgs<real> brick_args() {
+        BrickArgs<real> a{};
+        a.n = n_total; a.n_owned = n_owned;
+        a.rec = rec.ptr; a.te = te.ptr; a.perm = perm.ptr; a.start = start();
+        a.g = grid; a.bg = bgrid; a.tile_cap = tile_cap; a.own_cap = own_cap;
+        a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
+        a.rlist2 = (real)(rlist * rlist); a.model = model; a.pitch = pitch;
+        a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
+        return a;
+    }
+
+    template <class V, int MODE, int BM>
+    void launch_brick_kernel() {
+        auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM>;
+        allow_big_lds(kernel, lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_bytes, stream(), brick_args());
+    }
+
+    template <class V>
+    void launch_brick_force(int bitmask) {
+        if constexpr (std::is_same<V, BrickVariant<0>>::value) {
+            switch (bitmask) {
+                case 1: launch_brick_kernel<V, BRICK_FORCE, 1>(); return;
+                case 2: launch_brick_kernel<V, BRICK_FORCE, 2>(); return;
+                case 3: launch_brick_kernel<V, BRICK_FORCE, 3>(); return;
+                case 4: launch_brick_kernel<V, BRICK_FORCE, 4>(); return;
+                case 5: launch_brick_kernel<V, BRICK_FORCE, 5>(); return;
+                case 6: launch_brick_kernel<V, BRICK_FORCE, 6>(); return;
+                default: launch_brick_kernel<V, BRICK_FORCE, 7>(); return;
+            }
+        }
+        // tuning variants carry only the two masks the MD loop uses
+        if (bitmask == 1) launch_brick_kernel<V, BRICK_FORCE, 1>();
+        else launch_brick_kernel<V, BRICK_FORCE, 7>();
+    }
+
+    // brick decomposition + exact LDS tile capacity for the current cell populations; false if a
+    // tile cannot fit in LDS (then the direct kernels are used)
+    bool plan_bricks() {
+        bool ok = true;
+        with_brick_variant(variant, [&](auto v) {
+            using V = decltype(v);
+            using S = typename V::Shape;
+            bgrid.nb[0] = (grid.M[0] + S::BX - 1) / S::BX;
+            bgrid.nb[1] = (grid.M[1] + S::BY - 1) / S::BY;
+            bgrid.nb[2] = (grid.M[2] + S::BZ - 1) / S::BZ;
+            bgrid.nbricks = bgrid.nb[0] * bgrid.nb[1] * bgrid.nb[2];
+            bgrid.per_xcd = (bgrid.nbricks + NXCD - 1) / NXCD;
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 3, 0, 2 * sizeof(int), stream()));
+            hipLaunchKernelGGL((k_brick_tile_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
+                               grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], start(),
+                               flags.ptr + 3);
+            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 3, flags.ptr + 3, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+            tile_cap = std::max(64, (ctx->host_flags[3] + 15) / 16 * 16);
+            own_cap = std::max(64, (ctx->host_flags[4] + 15) / 16 * 16);
+            lds_bytes = brick_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
+            row_block = EPL * V::G;
+            ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
+        });
+        return ok;
+    }
+
     // ---------------------------------------------------------------- neighbour list
+    bool brick_active = false;
+
     void build_list() {
         const int n = n_total;
         if (stride == 0) {
@@ -218,17 +336,26 @@ struct NbSystem {
             double expect = n > 0 ? (4.0 / 3.0) * M_PI * rlist * rlist * rlist * (double)n / vol : 0.0;
             stride = (int)((expect * 1.3 + 24.0) / 16.0 + 1.0) * 16;
         }
+        brick_active = (path == PATH_BRICK) && n > 0 && plan_bricks();
+        if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
-            nbr.ensure((size_t)std::max(n, 1) * stride);
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 2 * sizeof(int), stream()));
-            if (n > 0)
-                hipLaunchKernelGGL((k_nbr_build<real>), dim3(blocks_for((size_t)n * WAVE, NBR_BLOCK)), dim3(NBR_BLOCK), 0,
-                                   stream(), n, n_owned, view(), perm.ptr, cell_sorted.ptr, start(), grid,
-                                   (real)(rlist * rlist), nbr.ptr, stride, cnt.ptr, flags.ptr);
-            // a build is rare (every ~10-20 steps): one blocking read-back of the overflow word
-            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, sizeof(int), hipMemcpyDeviceToHost, stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 3 * sizeof(int), stream()));
+            if (brick_active) {
+                nbr16.ensure((size_t)std::max(n, 1) * stride);
+                with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_BUILD, 0>(); });
+            } else {
+                nbr.ensure((size_t)std::max(n, 1) * stride);
+                if (n > 0)
+                    hipLaunchKernelGGL((k_nbr_build<real>), dim3(blocks_for((size_t)n * WAVE, NBR_BLOCK)), dim3(NBR_BLOCK),
+                                       0, stream(), n, n_owned, view(), perm.ptr, cell_sorted.ptr, start(), grid,
+                                       (real)(rlist * rlist), nbr.ptr, stride, cnt.ptr, flags.ptr);
+            }
+            // a build is rare (every ~10 steps): one blocking read-back of the overflow words
+            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+            EMDEE_REQUIRE(ctx->host_flags[2] == 0, EMDEE_ERR_OVERFLOW, "LDS tile overflow (%d records > %d)",
+                          ctx->host_flags[2], tile_cap);
             int needed = ctx->host_flags[0];
             if (needed <= stride) {
                 builds++;
@@ -236,13 +363,14 @@ struct NbSystem {
                 return;
             }
             stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
+            if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;
         }
         EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
     }
 
     // ---------------------------------------------------------------- forces
     template <int BM>
-    void launch_force() {
+    void launch_direct_force() {
         const int n = n_total;
         int nblocks = (n + FORCE_ATOMS - 1) / FORCE_ATOMS;
         int per_xcd = (nblocks + NXCD - 1) / NXCD;
@@ -256,14 +384,18 @@ struct NbSystem {
         EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of 1|2|4");
         if (n_total == 0 || bitmask == 0) return;
         Timed t(this, T_FORCE);
+        if (brick_active) {
+            with_brick_variant(variant, [&](auto v) { launch_brick_force<decltype(v)>(bitmask); });
+            return;
+        }
         switch (bitmask) {
-            case 1: launch_force<1>(); break;
-            case 2: launch_force<2>(); break;
-            case 3: launch_force<3>(); break;
-            case 4: launch_force<4>(); break;
-            case 5: launch_force<5>(); break;
-            case 6: launch_force<6>(); break;
-            default: launch_force<7>(); break;
+            case 1: launch_direct_force<1>(); break;
+            case 2: launch_direct_force<2>(); break;
+            case 3: launch_direct_force<3>(); break;
+            case 4: launch_direct_force<4>(); break;
+            case 5: launch_direct_force<5>(); break;
+            case 6: launch_direct_force<6>(); break;
+            default: launch_direct_force<7>(); break;
         }
     }
 
@@ -311,9 +443,13 @@ struct NbSystem {
         unsigned long long h[3] = {0, 0, 0};
         if (has_list && n_total > 0) {
             EMDEE_HIP_CHECK(hipMemsetAsync(stats.ptr, 0, 3 * sizeof(unsigned long long), stream()));
-            int nb = std::min((int)blocks_for(n_total, RED_BLOCK), RED_MAX_BLOCKS);
-            hipLaunchKernelGGL((k_list_stats<real>), dim3(nb), dim3(RED_BLOCK), 0, stream(), n_total, view(), nbr.ptr,
-                               stride, cnt.ptr, grid, model.rc2, count_pairs ? 1 : 0, stats.ptr);
+            if (brick_active) {
+                with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STATS, 0>(); });
+            } else {
+                int nb = std::min((int)blocks_for(n_total, RED_BLOCK), RED_MAX_BLOCKS);
+                hipLaunchKernelGGL((k_list_stats<real>), dim3(nb), dim3(RED_BLOCK), 0, stream(), n_total, view(), nbr.ptr,
+                                   stride, cnt.ptr, grid, model.rc2, count_pairs ? 1 : 0, stats.ptr);
+            }
             EMDEE_HIP_CHECK(hipMemcpyAsync(h, stats.ptr, sizeof(h), hipMemcpyDeviceToHost, stream()));
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
         }
@@ -327,8 +463,8 @@ struct NbSystem {
         if (n_total == 0) return;
         EMDEE_REQUIRE(!velocities || with_vel, EMDEE_ERR_STATE, "no velocities loaded");
         hipLaunchKernelGGL((k_unsort<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_owned, n_total, pitch,
-                           inv_perm.ptr, rec.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr, pos, velocities,
-                           forces, energies, virials);
+                           grid, img.ptr, inv_perm.ptr, rec.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr,
+                           pos, velocities, forces, energies, virials);
     }
 
     // operator path: does the cached list still cover these caller positions?
@@ -344,7 +480,7 @@ struct NbSystem {
     void refresh_user(const real *pos, const emdee_lj_atom *atoms) {
         if (n_total == 0) return;
         hipLaunchKernelGGL((k_refresh_positions<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
-                           perm.ptr, pos, atoms, rec.ptr, te.ptr);
+                           pitch, grid, perm.ptr, pos, atoms, xb.ptr, rec.ptr, te.ptr);
     }
 };
 

@@ -136,8 +136,9 @@ def test_neighbor_path_on_reference_fixture(emdee, oracle, dev, lj_sample, golde
         assert w.sum() == pytest.approx(-957.3125855282784, rel=1e-10)
         assert np.abs(f.sum(axis=0)).max() < 1e-9
     else:
+        # fp32 storage: ~1e-5 of the largest value (|W| reaches 50 here), 1e-4 on energies as in the reference
         assert np.abs(f - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
-        assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 2e-4
+        assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 1e-5 * np.abs(w0).max()
     st = tiles.stats()
     assert st["builds"] == 1 and st["max_count"] <= st["capacity"]
     off, nb = oracle.neighbor_list(x.astype(np.float64), 10.0, 3.0 + 0.3)
