@@ -11,12 +11,17 @@
 // LDS read.  The tile of a brick is a pure function of the cell populations, which are frozen
 // between rebuilds, so slots written by the build kernel stay valid for every force pass.
 //
-// Work split inside a workgroup: groups of G lanes share one atom (G = 16: one DPP row per
-// atom, 4 atoms per wavefront).  Lane l of the group takes neighbours l, l+G, l+2G, ...; the
-// row is stored LANE-MAJOR in blocks of 8 G entries so that those are 8 consecutive uint16 =
-// ONE 16-byte load per lane (256 contiguous bytes per atom for G = 16), issued one atom ahead of
-// the arithmetic.  Per-lane partial sums are combined with DPP row shifts (+ row broadcasts
-// for G > 16).  Owner-computes, full list: no atomics, no pre-zeroing.
+// Work split inside a workgroup: groups of G lanes share one atom (G = 8 or 16: half / one DPP
+// row per atom, 8 / 4 atoms per wavefront).  Lane l of the group takes neighbours l, l+G, l+2G,
+// ...; the row is stored LANE-MAJOR in blocks of 8 G entries so that those are 8 consecutive
+// uint16 = ONE 16-byte load per lane, issued one atom ahead of the arithmetic.  Per-lane partial
+// sums are combined with DPP row shifts.  Owner-computes, full list: no atomics, no pre-zeroing.
+//
+// k_brick_build keeps its tile as fp32 positions relative to the brick origin (16 B per record:
+// twice the occupancy of the fp64 tile) and tests r^2 < r_list^2 in fp32 first.  The fp32 result is
+// trusted only outside a rounding band whose width is a proven bound of the fp32 error; the few
+// pairs inside the band are re-tested with the exact fp64 records, so the neighbour set is
+// bit-identical to an all-fp64 build.
 //
 // Reference lines restated: pair function src/lennard_jones.jl:25-42 (lj_pair.hpp);
 // f_ij = W/r2 * r_ij and the half split of E, W per atom src/nonbonded.jl:136-145; the cell
@@ -28,7 +33,7 @@
 
 namespace emdee {
 
-enum BrickMode { BRICK_BUILD = 0, BRICK_FORCE = 1, BRICK_STATS = 2 };
+enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2 };
 
 constexpr int EPL = 8;   // neighbour entries per lane per 16-byte load
 
@@ -79,19 +84,45 @@ struct BrickArgs {
     int *cnt;
     int *flags;                // [0] row overflow (max count), [2] tile overflow
     real rlist2;
+    float margin;              // build: half-width of the fp32 rounding band around rlist2
     LJModel<real> model;
     size_t pitch;
     real *frc, *en, *vir;
     unsigned long long *stats; // BRICK_STATS: [0] entries, [1] max row, [2] in-cutoff entries
 };
 
-// bytes of dynamic LDS k_brick needs
+// ---- LDS tables shared by the build and force kernels ------------------------------------------
+template <class Shape, int THREADS>
+struct BrickTables {
+    static constexpr int NTC = Shape::NTC, NOC = Shape::NOC, NWAVES = THREADS / WAVE;
+    int *off;      // [NTC+1] tile-local first slot of each tile cell
+    int *gbeg;     // [NTC]   global (cell-order) first slot of each tile cell
+    int *shift;    // [NTC]   periodic image: 2 bits per dimension (0:-1, 1:0, 2:+1)
+    int *own;      // [NOC+1] prefix of own-cell populations
+    int *wtot;     // [NWAVES]
+    int2 *oinfo;   // [own_cap] per own atom {cell-order slot p, (row length or flag) << 16 | tile slot}
+    static constexpr size_t fixed_ints() { return (NTC + 4) + NTC + NTC + (NOC + 4) + ((NWAVES + 1) & ~1); }
+    static size_t bytes(int own_cap) { return ((fixed_ints() + 2 * (size_t)own_cap) * 4 + 15) & ~(size_t)15; }
+    __device__ __forceinline__ void carve(unsigned char *base) {
+        off = reinterpret_cast<int *>(base);
+        gbeg = off + (NTC + 4);
+        shift = gbeg + NTC;
+        own = shift + NTC;
+        wtot = own + (NOC + 4);
+        oinfo = reinterpret_cast<int2 *>(wtot + ((NWAVES + 1) & ~1));
+    }
+};
+
+// bytes of dynamic LDS: force tile = HBM records (+ te plane for fp32); build tile = float4
 template <typename real, class Shape, int THREADS>
-static inline size_t brick_lds_bytes(int tile_cap, int own_cap) {
+static inline size_t brick_force_lds_bytes(int tile_cap, int own_cap) {
     size_t tile_bytes = (size_t)tile_cap * sizeof(Rec<real>);
     size_t te_bytes = sizeof(real) == 4 ? (((size_t)tile_cap * 4 + 15) & ~(size_t)15) : 0;
-    size_t ints = (Shape::NTC + 4) + Shape::NTC + Shape::NTC + (Shape::NOC + 4) + THREADS / WAVE + 2 + 2 * (size_t)own_cap;
-    return tile_bytes + te_bytes + ((ints * 4 + 15) & ~(size_t)15);
+    return tile_bytes + te_bytes + BrickTables<Shape, THREADS>::bytes(own_cap);
+}
+template <class Shape, int THREADS>
+static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap) {
+    return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap);
 }
 
 // position of the e-th neighbour inside a row: blocks of 8 G entries, lane-major inside a block,
@@ -123,43 +154,25 @@ __device__ __forceinline__ int pick16(const uint4 &q, int t) {   // t is a compi
     return (int)((t & 1) ? (w >> 16) : (w & 0xffffu));
 }
 
-template <typename real, class Shape, int THREADS, int G, int MODE, int BITMASK>
-__global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
-    constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC, NOC = Shape::NOC;
-    constexpr int NWAVES = THREADS / WAVE;
-    constexpr int GROUPS_PER_WAVE = WAVE / G;
-    constexpr int NGROUPS = NWAVES * GROUPS_PER_WAVE;
-    constexpr int BLK = EPL * G;
-
-    // All LDS lives in the dynamic region with 16-byte carve offsets (a static __shared__ in front
-    // would shift the base and put the ds_read_b128 gathers off their natural alignment).
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
-    const size_t tile_bytes = (size_t)a.tile_cap * sizeof(Rec<real>);
-    const size_t te_bytes = sizeof(real) == 4 ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
-    float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
-    int *s_int = reinterpret_cast<int *>(s_dyn + tile_bytes + te_bytes);
-    int *s_off = s_int;                    // [NTC+1] tile-local first slot of each tile cell
-    int *s_gbeg = s_off + (NTC + 4);       // [NTC]   global (cell-order) first slot of each tile cell
-    int *s_shift = s_gbeg + NTC;           // [NTC]   periodic image: 2 bits per dimension (0:-1, 1:0, 2:+1)
-    int *s_own = s_shift + NTC;            // [NOC+1] prefix of own-cell populations
-    int *s_wtot = s_own + (NOC + 4);       // [NWAVES]
-    // [own_cap] per own atom {cell-order slot p, (row length or active flag) << 16 | tile slot}
-    int2 *s_oinfo = reinterpret_cast<int2 *>(s_wtot + ((NWAVES + 1) & ~1));
-
+// Fills the tile-cell and own-cell tables of this block's brick.  Returns false when the block
+// has nothing to do.  Contains block barriers: every thread of the block must call it.
+template <typename real, class Shape, int THREADS>
+__device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const BrickTables<Shape, THREADS> &T, int &bxi,
+                                            int &byi, int &bzi, int &tile_n, int &n_own) {
+    constexpr int BX = Shape::BX, BY = Shape::BY, BZ = Shape::BZ, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC,
+                  NOC = Shape::NOC;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int lb = (blockIdx.x % NXCD) * a.bg.per_xcd + blockIdx.x / NXCD;   // XCD-contiguous brick order
-    if (lb >= a.bg.nbricks) return;
-    const int bxi = lb % a.bg.nb[0], byi = (lb / a.bg.nb[0]) % a.bg.nb[1], bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
+    if (lb >= a.bg.nbricks) return false;
+    bxi = lb % a.bg.nb[0]; byi = (lb / a.bg.nb[0]) % a.bg.nb[1]; bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
     const int Mx = a.g.M[0], My = a.g.M[1], Mz = a.g.M[2];
 
-    // ---- 1. tile cell table: population, global begin, periodic image --------------------------
     int my_cnt = 0;
     if (tid < NTC) {
         const int tx = tid % TX, ty = (tid / TX) % TY, tz = tid / (TX * TY);
-        int gx = bxi * BX - 1 + tx, gy = byi * BY - 1 + ty, gz = bzi * Shape::BZ - 1 + tz;
+        int gx = bxi * BX - 1 + tx, gy = byi * BY - 1 + ty, gz = bzi * BZ - 1 + tz;
         // own range may be clipped on the high side of a partial brick; halo = own range +- 1
-        const int ox1 = min(bxi * BX + BX, Mx), oy1 = min(byi * BY + BY, My), oz1 = min(bzi * Shape::BZ + Shape::BZ, Mz);
+        const int ox1 = min(bxi * BX + BX, Mx), oy1 = min(byi * BY + BY, My), oz1 = min(bzi * BZ + BZ, Mz);
         bool valid = gx <= ox1 && gy <= oy1 && gz <= oz1;
         int sh = 1 | (1 << 2) | (1 << 4);
         auto wrap = [&](int &c, int M, int per, int bit) {
@@ -178,8 +191,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             gb = a.start[c];
             my_cnt = a.start[c + 1] - gb;
         }
-        s_gbeg[tid] = gb;
-        s_shift[tid] = sh;
+        T.gbeg[tid] = gb;
+        T.shift[tid] = sh;
     }
     {   // exclusive scan of my_cnt over the first NTC threads (NTC <= THREADS)
         int inc = my_cnt;
@@ -188,56 +201,181 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             int t = __shfl_up(inc, off);
             if (lane >= off) inc += t;
         }
-        if (lane == WAVE - 1) s_wtot[wv] = inc;
+        if (lane == WAVE - 1) T.wtot[wv] = inc;
         __syncthreads();
         int woff = 0;
-        for (int w = 0; w < wv; w++) woff += s_wtot[w];
-        if (tid < NTC) s_off[tid] = woff + inc - my_cnt;
-        if (tid == NTC - 1) s_off[NTC] = woff + inc;
+        for (int w = 0; w < wv; w++) woff += T.wtot[w];
+        if (tid < NTC) T.off[tid] = woff + inc - my_cnt;
+        if (tid == NTC - 1) T.off[NTC] = woff + inc;
     }
     __syncthreads();
-    const int tile_n = s_off[NTC];
+    tile_n = T.off[NTC];
     if (tid == 0) {
         int acc = 0;
         for (int oc = 0; oc < NOC; oc++) {
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const int tc = (ox + 1) + TX * ((oy + 1) + TY * (oz + 1));
-            s_own[oc] = acc;
+            T.own[oc] = acc;
             // cells past the box edge of a partial brick hold halo images, not atoms of this brick
-            const bool mine = (bxi * BX + ox < Mx) && (byi * BY + oy < My) && (bzi * Shape::BZ + oz < Mz);
-            acc += mine ? (s_off[tc + 1] - s_off[tc]) : 0;
+            const bool mine = (bxi * BX + ox < Mx) && (byi * BY + oy < My) && (bzi * BZ + oz < Mz);
+            acc += mine ? (T.off[tc + 1] - T.off[tc]) : 0;
         }
-        s_own[NOC] = acc;
+        T.own[NOC] = acc;
     }
     __syncthreads();
-    const int n_own = s_own[NOC];
+    n_own = T.own[NOC];
     if (tile_n > a.tile_cap || n_own > a.own_cap) {   // cannot happen: the host sized both from k_brick_tile_max
         if (tid == 0) atomicMax(&a.flags[2], max(tile_n, n_own));
-        return;
+        return false;
     }
+    return n_own > 0;
+}
 
-    // own atom o -> (tile slot, cell-order slot)
-    auto locate = [&](int o, int &ti, int &p) {
-        int oc = 0;
+// own atom o -> own cell, tile slot, cell-order slot
+template <class Shape, int THREADS>
+__device__ __forceinline__ int brick_locate(const BrickTables<Shape, THREADS> &T, int o, int &ti, int &p) {
+    int oc = 0;
 #pragma unroll
-        for (int q = 1; q < NOC; q++) oc += (s_own[q] <= o) ? 1 : 0;
-        const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
-        const int tc = (ox + 1) + TX * ((oy + 1) + TY * (oz + 1));
-        const int kk = o - s_own[oc];
-        ti = s_off[tc] + kk;
-        p = s_gbeg[tc] + kk;
-        return oc;
-    };
+    for (int q = 1; q < Shape::NOC; q++) oc += (T.own[q] <= o) ? 1 : 0;
+    const int ox = oc % Shape::BX, oy = (oc / Shape::BX) % Shape::BY, oz = oc / (Shape::BX * Shape::BY);
+    const int tc = (ox + 1) + Shape::TX * ((oy + 1) + Shape::TY * (oz + 1));
+    const int kk = o - T.own[oc];
+    ti = T.off[tc] + kk;
+    p = T.gbeg[tc] + kk;
+    return oc;
+}
 
-    // ---- 2. stage the tile: HBM -> LDS, unit stride inside each cell run, image shift applied ---
+// tile slot s -> tile cell (largest tc with off[tc] <= s)
+template <class Shape, int THREADS>
+__device__ __forceinline__ int brick_cell_of_slot(const BrickTables<Shape, THREADS> &T, int s) {
+    int lo = 0, hi = Shape::NTC;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (T.off[mid] <= s) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------ build
+template <typename real, class Shape, int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
+    constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY;
+    constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    float4 *tile = reinterpret_cast<float4 *>(s_dyn);   // {x, y, z relative to the brick origin, cell-order slot}
+    BrickTables<Shape, THREADS> T;
+    T.carve(s_dyn + (size_t)a.tile_cap * 16);
+    int bxi, byi, bzi, tile_n, n_own;
+    if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+
+    // brick origin: fp64 boxes are re-based here so that fp32 coordinates stay small
+    real org[3] = {0, 0, 0};
+    if (sizeof(real) == 8) {
+        org[0] = a.g.lo[0] + (real)(bxi * BX) * (a.g.len[0] / (real)a.g.M[0]);
+        org[1] = a.g.lo[1] + (real)(byi * BY) * (a.g.len[1] / (real)a.g.M[1]);
+        org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
+    }
     for (int s = tid; s < tile_n; s += THREADS) {
-        int lo = 0, hi = NTC;   // largest tc with s_off[tc] <= s
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_off[mid] <= s) lo = mid; else hi = mid;
+        const int tc = brick_cell_of_slot(T, s);
+        const int gp = T.gbeg[tc] + (s - T.off[tc]);
+        const int sh = T.shift[tc];
+        const Rec<real> r = a.rec[gp];
+        float4 q;
+        q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
+        q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
+        q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
+        q.w = __int_as_float(gp);
+        tile[s] = q;
+    }
+    for (int o = tid; o < n_own; o += THREADS) {
+        int ti, p;
+        brick_locate(T, o, ti, p);
+        T.oinfo[o] = make_int2(p, ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+    }
+    __syncthreads();
+
+    const int gl = lane & (G - 1);
+    const int gid = (tid / WAVE) * (WAVE / G) + lane / G;
+    const float rl2 = (float)a.rlist2;
+    const float lo2 = rl2 - a.margin, hi2 = rl2 + a.margin;   // margin == 0 for fp32 boxes: the fp32 test is exact
+    for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
+        const int o = ob + gid;
+        const bool have = o < n_own;
+        int ti = 0, p = 0, oc = 0;
+        if (have) oc = brick_locate(T, o, ti, p);
+        const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+        const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
+        const float4 qi = tile[ti];
+        unsigned short *row = a.nbr + (size_t)p * a.stride;
+        int count = 0;
+#pragma unroll 1
+        for (int dz = -1; dz <= 1; dz++) {
+#pragma unroll 1
+            for (int dy = -1; dy <= 1; dy++) {
+                const int tcr = ox + TX * ((oy + 1 + dy) + TY * (oz + 1 + dz));   // cell x-1 of that tile row
+                const int c0 = T.off[tcr];
+                const int span = act ? T.off[tcr + 3] - c0 : 0;                    // cells x-1, x, x+1: contiguous
+                const int wspan = wave_group_max<G>(span);
+                for (int cb = 0; cb < wspan; cb += G) {
+                    const int c = c0 + cb + gl;
+                    bool pass = false;
+                    if (cb + gl < span && c != ti) {
+                        const float4 qj = tile[c];
+                        const float dx = qi.x - qj.x, dy2 = qi.y - qj.y, dz2 = qi.z - qj.z;
+                        const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+                        pass = d2 < lo2;
+                        if (sizeof(real) == 8 && __builtin_expect(!pass && d2 <= hi2, 0)) {
+                            // inside the fp32 rounding band: decide with the exact fp64 records
+                            const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
+                            const int sh = T.shift[tc];
+                            const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(qj.w)];
+                            const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
+                            const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
+                            const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
+                            pass = ex * ex + ey * ey + ez * ez < a.rlist2;
+                        }
+                    }
+                    const unsigned long long bits = group_bits<G>(__ballot(pass), lane);
+                    if (pass) {
+                        const int e = count + __popcll(bits & ((1ull << gl) - 1ull));
+                        if (e < a.stride) row[row_position<G>(e)] = (unsigned short)c;
+                    }
+                    count += __popcll(bits);
+                }
+            }
         }
-        const int gp = s_gbeg[lo] + (s - s_off[lo]);
-        const int sh = s_shift[lo];
+        if (have && gl == 0) {
+            a.cnt[p] = act ? min(count, a.stride) : 0;
+            if (count > a.stride) atomicMax(&a.flags[0], count);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ force / stats
+template <typename real, class Shape, int THREADS, int G, int MODE, int BITMASK>
+__global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
+    constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
+    constexpr int BLK = EPL * G;
+
+    // All LDS lives in the dynamic region with 16-byte carve offsets (a static __shared__ in front
+    // would shift the base and put the ds_read_b128 gathers off their natural alignment).
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
+    const size_t tile_bytes = (size_t)a.tile_cap * sizeof(Rec<real>);
+    const size_t te_bytes = sizeof(real) == 4 ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
+    float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
+    BrickTables<Shape, THREADS> T;
+    T.carve(s_dyn + tile_bytes + te_bytes);
+    int bxi, byi, bzi, tile_n, n_own;
+    if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+
+    // ---- stage the tile: HBM -> LDS, unit stride inside each cell run, image shift applied ------
+    for (int s = tid; s < tile_n; s += THREADS) {
+        const int tc = brick_cell_of_slot(T, s);
+        const int gp = T.gbeg[tc] + (s - T.off[tc]);
+        const int sh = T.shift[tc];
         Rec<real> r = a.rec[gp];
         r.x += (real)((sh & 3) - 1) * a.g.len[0];
         r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
@@ -248,76 +386,27 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // per own atom: where it lives and its row length (0 for ghosts: they own no row, get no force)
     for (int o = tid; o < n_own; o += THREADS) {
         int ti, p;
-        locate(o, ti, p);
-        const bool act = a.perm[p] < a.n_owned;
-        const int m = (MODE == BRICK_BUILD) ? (act ? 1 : 0) : (act ? a.cnt[p] : 0);
-        s_oinfo[o] = make_int2(p, (m << 16) | ti);
+        brick_locate(T, o, ti, p);
+        const int m = a.perm[p] < a.n_owned ? a.cnt[p] : 0;
+        T.oinfo[o] = make_int2(p, (m << 16) | ti);
     }
     __syncthreads();
 
-    // ---- 3. own atoms: one G-lane group per atom ------------------------------------------------
-    const int gl = lane & (G - 1);                       // lane inside the group
-    const int gid = wv * GROUPS_PER_WAVE + lane / G;     // group inside the block
+    // ---- own atoms: one G-lane group per atom; the NEXT atom's indices are fetched meanwhile -----
+    const int gl = lane & (G - 1);                            // lane inside the group
+    const int gid = (tid / WAVE) * (WAVE / G) + lane / G;     // group inside the block
     unsigned long long st_entries = 0, st_inside = 0;
     int st_max = 0;
-
-    if (MODE == BRICK_BUILD) {
-        for (int ob = 0; ob < n_own; ob += NGROUPS) {    // wave-uniform trip count
-            const int o = ob + gid;
-            const bool have = o < n_own;
-            int ti = 0, p = 0, oc = 0;
-            if (have) oc = locate(o, ti, p);
-            const bool act = have && (s_oinfo[o].y >> 16) != 0;
-            const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
-            real xi, yi, zi, hs_i, te_i;
-            tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
-            unsigned short *row = a.nbr + (size_t)p * a.stride;
-            int count = 0;
-#pragma unroll 1
-            for (int dz = -1; dz <= 1; dz++) {
-#pragma unroll 1
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int tcr = ox + TX * ((oy + 1 + dy) + TY * (oz + 1 + dz));   // cell x-1 of that tile row
-                    const int c0 = s_off[tcr];
-                    const int span = act ? s_off[tcr + 3] - c0 : 0;                     // cells x-1, x, x+1: contiguous
-                    const int wspan = wave_group_max<G>(span);
-                    for (int cb = 0; cb < wspan; cb += G) {
-                        const int c = c0 + cb + gl;
-                        bool pass = false;
-                        if (cb + gl < span && c != ti) {
-                            real xj, yj, zj, hj, tj;
-                            tile_load<real>(tile, tile_te, c, xj, yj, zj, hj, tj);
-                            const real dx = xi - xj, dy2 = yi - yj, dz2 = zi - zj;
-                            pass = dx * dx + dy2 * dy2 + dz2 * dz2 < a.rlist2;
-                        }
-                        const unsigned long long bits = group_bits<G>(__ballot(pass), lane);
-                        if (pass) {
-                            const int e = count + __popcll(bits & ((1ull << gl) - 1ull));
-                            if (e < a.stride) row[row_position<G>(e)] = (unsigned short)c;
-                        }
-                        count += __popcll(bits);
-                    }
-                }
-            }
-            if (have && gl == 0) {
-                a.cnt[p] = act ? min(count, a.stride) : 0;
-                if (count > a.stride) atomicMax(&a.flags[0], count);
-            }
-        }
-        return;
-    }
-
-    // FORCE / STATS: indices of the NEXT atom are fetched while the current one is being computed
     auto fetch = [&](int o) {
         uint4 q = make_uint4(0, 0, 0, 0);
-        if (o < n_own) q = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)s_oinfo[o].x * a.stride + gl * EPL);
+        if (o < n_own) q = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)T.oinfo[o].x * a.stride + gl * EPL);
         return q;
     };
     uint4 nxt = fetch(gid);
-    for (int ob = 0; ob < n_own; ob += NGROUPS) {        // wave-uniform trip count
+    for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
         const int o = ob + gid;
         const bool have = o < n_own;
-        const int2 info = have ? s_oinfo[o] : make_int2(0, 0);
+        const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
         const int p = info.x, ti = info.y & 0xffff, m = (int)((unsigned)info.y >> 16);
         uint4 cur = nxt;
         nxt = fetch(o + NGROUPS);
@@ -332,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             }
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-                if (b0 + t * G >= wm) break;             // wave-uniform
+                if (b0 + t * G >= wm) break;                  // wave-uniform
                 if (b0 + t * G + gl < m) {
                     const int sj = pick16(cur, t);
                     real xj, yj, zj, hs_j, te_j;
@@ -341,12 +430,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     const real r2 = dx * dx + dy * dy + dz * dz;
                     if (MODE == BRICK_STATS) {
                         st_inside += (r2 < a.model.rc2) ? 1ull : 0ull;
-                    } else if (r2 < a.model.rc2) {       // strict test (Q2)
+                    } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
                         real E, W;
                         lj_interaction(r2, inv_r2, a.model, hs_i, te_i, hs_j, te_j, E, W);
                         if (BITMASK & EMDEE_FORCES) {
-                            const real wr2 = W * inv_r2;   // src/nonbonded.jl:139
+                            const real wr2 = W * inv_r2;      // src/nonbonded.jl:139
                             fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
                         }
                         if (BITMASK & EMDEE_ENERGIES) e += E;
@@ -382,7 +471,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 }
 
 // Largest tile (brick + halo population) and largest own population over all bricks -> sizes the
-// dynamic LDS of k_brick.  out[0] = max tile, out[1] = max own.
+// dynamic LDS of the brick kernels.  out[0] = max tile, out[1] = max own.
 template <class Shape>
 __global__ void k_brick_tile_max(BrickGrid bg, int Mx, int My, int Mz, int px, int py, int pz,
                                  const int *__restrict__ start, int *__restrict__ out) {

@@ -102,7 +102,8 @@ struct NbSystem {
     int variant = 0;
     BrickGrid bgrid{};
     int tile_cap = 0, own_cap = 0, row_block = 1;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_build_bytes = 0;
+    float build_margin = 0.f;
 
     DevBuf<Rec<real>> rec, rec2;
     DevBuf<float> te, te2;
@@ -269,7 +270,7 @@ struct NbSystem {
         a.rec = rec.ptr; a.te = te.ptr; a.perm = perm.ptr; a.start = start();
         a.g = grid; a.bg = bgrid; a.tile_cap = tile_cap; a.own_cap = own_cap;
         a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
-        a.rlist2 = (real)(rlist * rlist); a.model = model; a.pitch = pitch;
+        a.rlist2 = (real)(rlist * rlist); a.margin = build_margin; a.model = model; a.pitch = pitch;
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         return a;
     }
@@ -319,9 +320,21 @@ struct NbSystem {
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
             tile_cap = std::max(64, (ctx->host_flags[3] + 15) / 16 * 16);
             own_cap = std::max(64, (ctx->host_flags[4] + 15) / 16 * 16);
-            lds_bytes = brick_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
+            lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
+            lds_build_bytes = brick_build_lds_bytes<S, V::THREADS>(tile_cap, own_cap);
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
+            // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
+            // cmax, so each is off by <= cmax 2^-24 after rounding; with |d| <= r_list per component the
+            // error of d^2 is below 4 sqrt(3) r_list cmax 2^-24 + 4 r_list^2 2^-23.  Band = 4 x that bound.
+            build_margin = 0.f;
+            if (sizeof(real) == 8) {
+                double cmax = 0.0;
+                const int B[3] = {S::BX, S::BY, S::BZ};
+                for (int d = 0; d < 3; d++) cmax = std::max(cmax, (B[d] + 2) * len[d] / grid.M[d]);
+                const double bound = 4.0 * 1.7320508 * rlist * cmax * std::ldexp(1.0, -24) + 4.0 * rlist * rlist * std::ldexp(1.0, -23);
+                build_margin = (float)(4.0 * bound);
+            }
         });
         return ok;
     }
@@ -343,7 +356,13 @@ struct NbSystem {
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 3 * sizeof(int), stream()));
             if (brick_active) {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
-                with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_BUILD, 0>(); });
+                with_brick_variant(variant, [&](auto v) {
+                    using V = decltype(v);
+                    auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G>;
+                    allow_big_lds(kernel, lds_build_bytes);
+                    hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(),
+                                       brick_args());
+                });
             } else {
                 nbr.ensure((size_t)std::max(n, 1) * stride);
                 if (n > 0)
