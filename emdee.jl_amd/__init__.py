@@ -22,6 +22,7 @@ from .nonbonded import (ENERGIES, FORCES, VIRIALS, WAVESIZE, AllPairsTiles,     
                         nonbonded_computation_tiles)
 from .verlet import VelocityVerlet                                              # noqa: E402
 from . import synthetic                                                         # noqa: E402
+from . import domain                                                            # noqa: E402
 
 __all__ = ["LennardJonesModel", "LennardJonesAtom", "LJAtom", "lennard_jones_atoms", "interaction",
            "FORCES", "ENERGIES", "VIRIALS", "Val", "nonbonded_computation_tiles", "compute_nonbonded_",

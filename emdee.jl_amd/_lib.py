@@ -71,7 +71,7 @@ SIGNATURES = {
     "emdee_md_kick": [_p, _dbl],
     "emdee_md_needs_rebuild": [_p, C.POINTER(_i32)],
     "emdee_md_rebuild": [_p],
-    "emdee_md_pack_positions": [_p, _p, _i32, _d3, _p],
+    "emdee_md_pack_positions": [_p, _p, _p, _i32, _d3, _i32, _p],
     "emdee_md_unpack_ghosts": [_p, _p, _i32, _i32],
     "emdee_md_energies": [_p, _d3],
     "emdee_md_nbr_stats": [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)],

@@ -333,12 +333,14 @@ int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag) {
 int32_t emdee_md_rebuild(emdee_md *md) {
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->rebuild(); });
 }
-int32_t emdee_md_pack_positions(emdee_md *md, const int32_t *ids_dev, int32_t n, const double shift[3], void *buf_dev) {
+int32_t emdee_md_pack_positions(emdee_md *md, const int32_t *ids_dev, const int32_t *codes_dev, int32_t n,
+                                const double *shifts, int32_t n_shifts, void *buf_dev) {
     return guarded([&] {
         REQUIRE_PTR(md, "md");
-        REQUIRE_PTR(shift, "shift");
+        REQUIRE_PTR(shifts, "shifts");
+        EMDEE_REQUIRE(n_shifts >= 1 && n_shifts <= 27, EMDEE_ERR_INVALID, "pack_positions: n_shifts must be in 1..27");
         EMDEE_REQUIRE(n == 0 || (ids_dev && buf_dev), EMDEE_ERR_INVALID, "pack_positions: NULL array");
-        md->impl->pack_positions(ids_dev, n, shift, buf_dev);
+        md->impl->pack_positions(ids_dev, codes_dev, n, shifts, n_shifts, buf_dev);
     });
 }
 int32_t emdee_md_unpack_ghosts(emdee_md *md, const void *buf_dev, int32_t first, int32_t n) {

@@ -33,7 +33,8 @@ struct IMd {
     virtual void kick(double dt) = 0;
     virtual bool needs_rebuild() = 0;
     virtual void rebuild() = 0;
-    virtual void pack_positions(const int32_t *ids, int n, const double shift[3], void *buf) = 0;
+    virtual void pack_positions(const int32_t *ids, const int32_t *codes, int n, const double *shifts, int n_shifts,
+                                void *buf) = 0;
     virtual void unpack_ghosts(const void *buf, int first, int n) = 0;
     virtual void energies(double out[3]) = 0;
     virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;

@@ -193,12 +193,16 @@ struct MdImpl : IMd {
         current_mask = 0;
         EMDEE_HIP_CHECK(hipGetLastError());
     }
-    void pack_positions(const int32_t *ids, int n, const double shift[3], void *buf) override {
+    void pack_positions(const int32_t *ids, const int32_t *codes, int n, const double *shifts, int n_shifts,
+                        void *buf) override {
         use_device(sys.ctx);
         EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
         if (n <= 0) return;
-        hipLaunchKernelGGL((k_pack_positions<real>), dim3(blocks_for(n, 256)), dim3(256), 0, sys.stream(), n, ids,
-                           sys.inv_perm.ptr, sys.rec.ptr, (real)shift[0], (real)shift[1], (real)shift[2], (real *)buf);
+        ShiftTable<real> tab{};
+        for (int k = 0; k < n_shifts; k++)
+            for (int d = 0; d < 3; d++) tab.s[k][d] = (real)shifts[3 * k + d];
+        hipLaunchKernelGGL((k_pack_positions<real>), dim3(blocks_for(n, 256)), dim3(256), 0, sys.stream(), n, ids, codes,
+                           n_shifts, sys.inv_perm.ptr, sys.rec.ptr, tab, (real *)buf);
     }
     void unpack_ghosts(const void *buf, int first, int n) override {
         use_device(sys.ctx);

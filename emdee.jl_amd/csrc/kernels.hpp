@@ -563,12 +563,20 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, 
 // halo exchange helpers: gather positions (+ periodic shift) of listed caller ids;
 // scatter received positions into ghost records
 template <typename real>
-__global__ void k_pack_positions(int n, const int *__restrict__ ids, const int *__restrict__ inv_perm,
-                                 const Rec<real> *__restrict__ rec, real sx, real sy, real sz, real *__restrict__ buf) {
+struct ShiftTable {
+    real s[27][3];
+};
+
+template <typename real>
+__global__ void k_pack_positions(int n, const int *__restrict__ ids, const int *__restrict__ codes, int n_shifts,
+                                 const int *__restrict__ inv_perm, const Rec<real> *__restrict__ rec,
+                                 ShiftTable<real> tab, real *__restrict__ buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Rec<real> r = rec[inv_perm[ids[k]]];
-    buf[3 * (size_t)k] = r.x + sx; buf[3 * (size_t)k + 1] = r.y + sy; buf[3 * (size_t)k + 2] = r.z + sz;
+    int c = codes ? codes[k] : 0;
+    c = min(max(c, 0), n_shifts - 1);
+    buf[3 * (size_t)k] = r.x + tab.s[c][0]; buf[3 * (size_t)k + 1] = r.y + tab.s[c][1]; buf[3 * (size_t)k + 2] = r.z + tab.s[c][2];
 }
 
 template <typename real>

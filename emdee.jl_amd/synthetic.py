@@ -81,9 +81,41 @@ def velocities(N, temperature=1.0, seed=SEED):
     return v
 
 
+def fcc_block(ncells, block_lo, block_n, rho=RHO, jitter=JITTER, seed=SEED):
+    """Atoms of the sub-block of fcc cells [block_lo, block_lo + block_n) of a box of ncells = (nx, ny, nz)
+    cells (one rank's brick of a decomposed run).  Global atom id = 4 (cx + nx (cy + ny cz)) + b, so the
+    jitter stream does not depend on the decomposition; for a cubic box and the whole box as the block
+    this is fcc_positions(n) up to atom order.  Returns (pos (n, 3), gid (n,) int64, lengths (3,))."""
+    nx, ny, nz = (int(v) for v in ncells)
+    a = (4.0 / rho) ** (1.0 / 3.0)
+    bx, by, bz = (int(v) for v in block_n)
+    lx, ly, lz = (int(v) for v in block_lo)
+    cz, cy, cx = np.meshgrid(np.arange(lz, lz + bz), np.arange(ly, ly + by), np.arange(lx, lx + bx), indexing="ij")
+    cell = (cx + nx * (cy + ny * cz)).reshape(-1).astype(np.int64)
+    cxyz = np.stack([cx.reshape(-1), cy.reshape(-1), cz.reshape(-1)], axis=1).astype(np.float64)
+    gid = (4 * cell[:, None] + np.arange(4, dtype=np.int64)[None, :]).reshape(-1)
+    base = (cxyz[:, None, :] + FCC_BASIS[None, :, :]).reshape(-1, 3)
+    ctr = (3 * gid)[:, None] + np.arange(3, dtype=np.int64)[None, :]
+    pos = base * a + jitter * (uniform(seed, ctr) - 0.5)
+    return pos, gid, np.array([nx * a, ny * a, nz * a])
+
+
+def raw_normals(gid, N_global, seed=SEED):
+    """The Box-Muller normals velocities() assigns to atoms gid of an N_global-atom box, before the
+    centre-of-mass and temperature corrections (which need global sums)."""
+    gid = np.asarray(gid, dtype=np.int64)
+    m = (3 * gid)[:, None] + np.arange(3, dtype=np.int64)[None, :]
+    k, odd = m >> 1, (m & 1).astype(bool)
+    u1 = uniform(seed, 3 * N_global + 2 * k)
+    u2 = uniform(seed, 3 * N_global + 2 * k + 1)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))
+    return np.where(odd, r * np.sin(2.0 * np.pi * u2), r * np.cos(2.0 * np.pi * u2))
+
+
 def mixture_types(N, seed=SEED_TYPES):
-    """0/1 species labels, ~50:50 (config C5)."""
-    return (splitmix64(np.arange(N, dtype=np.uint64) ^ np.uint64(seed)) & np.uint64(1)).astype(np.int32)
+    """0/1 species labels, ~50:50 (config C5). N: atom count, or an array of global atom ids."""
+    ids = np.arange(N, dtype=np.uint64) if np.isscalar(N) else np.asarray(N).astype(np.uint64)
+    return (splitmix64(ids ^ np.uint64(seed)) & np.uint64(1)).astype(np.int32)
 
 
 def mixture_parameters(types, eps=(1.0, 0.5), sigma=(1.0, 0.88)):

@@ -72,12 +72,16 @@ class VelocityVerlet:
     def rebuild_(self):
         _lib.call("emdee_md_rebuild", self._handle)
 
-    def pack_positions(self, ids, shift, out=None):
+    def pack_positions(self, ids, shifts, codes=None, out=None):
+        """Positions of caller-order ids (int32 GPU tensor) plus shifts[codes[k]] (flat list of 3-vectors;
+        codes None: every atom uses shifts[0:3]) -> (n, 3) buffer for the halo exchange."""
         n = ids.shape[0]
         if out is None:
             out = torch.empty((n, 3), dtype=self.dtype, device=self.device)
-        _lib.call("emdee_md_pack_positions", self._handle, C.c_void_p(ids.data_ptr()), n,
-                  (C.c_double * 3)(*[float(s) for s in shift]), C.c_void_p(out.data_ptr()))
+        flat = [float(s) for s in shifts]
+        _lib.call("emdee_md_pack_positions", self._handle, C.c_void_p(ids.data_ptr()),
+                  C.c_void_p(codes.data_ptr()) if codes is not None else None, n,
+                  (C.c_double * len(flat))(*flat), len(flat) // 3, C.c_void_p(out.data_ptr()))
         return out
 
     def unpack_ghosts_(self, buf, first):

@@ -193,11 +193,12 @@ int32_t emdee_md_kick(emdee_md *md, double dt);              /* v += (dt/2m) f *
 int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag);
 /* re-bin, re-sort and rebuild the neighbour list from the current positions */
 int32_t emdee_md_rebuild(emdee_md *md);
-/* halo: gather positions of the listed atoms (caller-order ids, dev int32[n]) plus a shift
- * into buf (3 n reals), and scatter received positions into ghost slots first..first+n-1
- * (ghost-relative). */
-int32_t emdee_md_pack_positions(emdee_md *md, const int32_t *ids_dev, int32_t n, const double shift[3],
-                                void *buf_dev);
+/* halo: gather positions of the listed atoms (caller-order ids, dev int32[n]) into buf (3 n
+ * reals), each plus the periodic-image shift shifts[3 codes[k] .. +2] (codes_dev: dev int32[n],
+ * NULL = every atom uses shifts[0..2]; n_shifts <= 27 rows of 3 doubles on the HOST); and scatter
+ * received positions into ghost slots first..first+n-1 (ghost-relative). */
+int32_t emdee_md_pack_positions(emdee_md *md, const int32_t *ids_dev, const int32_t *codes_dev, int32_t n,
+                                const double *shifts, int32_t n_shifts, void *buf_dev);
 int32_t emdee_md_unpack_ghosts(emdee_md *md, const void *buf_dev, int32_t first, int32_t n);
 /* totals over owned atoms: out[0] = potential energy (sum of per-atom halves), out[1] =
  * kinetic energy, out[2] = virial sum.  Evaluates energies/virials if needed. Blocking. */
