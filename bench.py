@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--mixture", action="store_true", help="binary LJ mixture (config 5)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="0 = displacement trigger; k = fixed cadence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged halo, for rehearsals")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU rehearsal, with --backend gloo)")
     ap.add_argument("--cpu-sample-cells", type=int, default=63)
     return ap.parse_args()
 
@@ -117,13 +120,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                              % (args.gpus, args.gpus))
+    if args.share_gpu:
+        local_rank = 0                     # rehearsal on a 1-GPU box: all ranks on cuda:0 (needs --backend gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    cdev = dev                             # where the small collective tensors live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+            cdev = torch.device("cpu")
 
     w = 8 if args.precision == "f64" else 4
     tdtype = torch.float64 if w == 8 else torch.float32
@@ -141,9 +151,9 @@ def main():
         engine = md
         parallelism = "single-gpu"
     else:
-        from __graft_entry__ import load_package as _lp  # noqa: F401
         domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
-                                                       skin=args.skin, mixture=args.mixture)
+                                                       skin=args.skin, mixture=args.mixture, pkg=pkg,
+                                                       transport="device" if args.backend == "nccl" else "host")
         N_rank, N_total = domain.n_owned, domain.n_global
         run = lambda k: domain.step_(k, args.dt, args.rebuild_every)
         engine = domain.md
@@ -164,7 +174,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
 
@@ -174,7 +184,7 @@ def main():
     stats = engine.nbr_stats()
     pairs = engine.count_pairs()
     if dist is not None:
-        tp = torch.tensor([pairs], dtype=torch.int64, device=dev)
+        tp = torch.tensor([pairs], dtype=torch.int64, device=cdev)
         dist.all_reduce(tp)
         pairs = int(tp.item())
     ep, ek, vir = engine.totals()

@@ -281,7 +281,7 @@ class DecomposedVerlet:
 
     @classmethod
     def synthetic(cls, cells, world, rank, device, model, precision=torch.float64, skin=0.3, mixture=False,
-                  temperature=1.0, pkg=None, group=None):
+                  temperature=1.0, pkg=None, group=None, transport="device"):
         """Weak-scaling synthetic box: every rank generates (and initially owns) a cells^3-cell fcc brick
         of the global (g_x cells, g_y cells, g_z cells) lattice.  Velocities get the global centre-of-mass
         and temperature corrections through two small all-reduces."""
@@ -300,16 +300,18 @@ class DecomposedVerlet:
             atoms = pkg.lennard_jones_atoms(eps, sigma)
         else:
             atoms = pkg.lennard_jones_atoms(1.0, 1.0, pos.shape[0])
-        sums = torch.tensor(np.concatenate([vel.sum(axis=0), [0.0]]), dtype=torch.float64, device=device)
+        cdev = device if transport == "device" else "cpu"
+        sums = torch.tensor(np.concatenate([vel.sum(axis=0), [0.0]]), dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(sums, group=group)
         vel = vel - (sums[:3].cpu().numpy() / n_global)
-        ke = torch.tensor([0.5 * float(np.sum(vel * vel))], dtype=torch.float64, device=device)
+        ke = torch.tensor([0.5 * float(np.sum(vel * vel))], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(ke, group=group)
         vel *= math.sqrt(temperature * max(3 * n_global - 3, 1) / (2.0 * ke.item()))
         rc = math.sqrt(model.rc2)
-        plan = DomainPlan(lengths, rc + skin, world=world, rank=rank, device=device, group=group, grid=grid)
+        plan = DomainPlan(lengths, rc + skin, world=world, rank=rank, device=device, group=group, grid=grid,
+                          transport=transport)
         x = torch.from_numpy(pos).to(device)
         v = torch.from_numpy(vel).to(device)
         a = pkg.cu(atoms, device)
