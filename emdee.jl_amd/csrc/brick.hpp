@@ -397,33 +397,40 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;     // group inside the block
     unsigned long long st_entries = 0, st_inside = 0;
     int st_max = 0;
+    // The first NPF blocks of a row (128 entries: every row of the LJ boxes) are prefetched.
+    constexpr int NPF = (BLK >= 128) ? 1 : 128 / BLK;
+    struct IdxBuf { uint4 q[NPF]; };
     auto fetch = [&](int o) {
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (o < n_own) q = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)T.oinfo[o].x * a.stride + gl * EPL);
-        return q;
+        IdxBuf b;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) b.q[k] = make_uint4(0, 0, 0, 0);
+        if (o < n_own) {
+            const unsigned short *row = a.nbr + (size_t)T.oinfo[o].x * a.stride + gl * EPL;
+#pragma unroll
+            for (int k = 0; k < NPF; k++)
+                if (k * BLK < a.stride) b.q[k] = *reinterpret_cast<const uint4 *>(row + k * BLK);
+        }
+        return b;
     };
-    uint4 nxt = fetch(gid);
+    IdxBuf nxt = fetch(gid);
     for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
         const int o = ob + gid;
         const bool have = o < n_own;
         const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
         const int p = info.x, ti = info.y & 0xffff, m = (int)((unsigned)info.y >> 16);
-        uint4 cur = nxt;
+        const IdxBuf cur = nxt;
         nxt = fetch(o + NGROUPS);
         const int wm = wave_group_max<G>(m);
         real xi, yi, zi, hs_i, te_i;
         tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
-        for (int b0 = 0; b0 < wm; b0 += BLK) {
-            if (b0 > 0) {   // rows longer than one block (rare): synchronous reload
-                cur = make_uint4(0, 0, 0, 0);
-                if (b0 < m) cur = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + gl * EPL);
-            }
+        // one block of 8 G neighbours: lane gl holds entries b0 + gl + t G, t = 0..7, in q
+        auto block = [&](const uint4 &q, int b0) {
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
                 if (b0 + t * G >= wm) break;                  // wave-uniform
                 if (b0 + t * G + gl < m) {
-                    const int sj = pick16(cur, t);
+                    const int sj = pick16(q, t);
                     real xj, yj, zj, hs_j, te_j;
                     tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
                     const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
@@ -443,6 +450,14 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     }
                 }
             }
+        };
+#pragma unroll
+        for (int k = 0; k < NPF; k++)
+            if (k * BLK < wm) block(cur.q[k], k * BLK);
+        for (int b0 = NPF * BLK; b0 < wm; b0 += BLK) {        // longer rows (rare): synchronous load
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (b0 < m) q = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + gl * EPL);
+            block(q, b0);
         }
         if (MODE == BRICK_STATS) {
             if (gl == 0) { st_entries += (unsigned long long)m; st_max = max(st_max, m); }
