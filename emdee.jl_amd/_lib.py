@@ -66,8 +66,8 @@ SIGNATURES = {
     "emdee_md_set_state": [_p, _i32, _i32, _p, _p, _p, _p],
     "emdee_md_get_state": [_p, _p, _p, _p, _p, _p],
     "emdee_md_step": [_p, _i32, _dbl, _i32],
-    "emdee_md_kick_drift": [_p, _dbl],
-    "emdee_md_forces": [_p, _i32],
+    "emdee_md_kick_drift": [_p, _dbl, _dbl],
+    "emdee_md_forces": [_p, _i32, _i32],
     "emdee_md_kick": [_p, _dbl],
     "emdee_md_needs_rebuild": [_p, C.POINTER(_i32)],
     "emdee_md_rebuild": [_p],

@@ -49,7 +49,16 @@ struct BrickGrid {
     int nb[3];         // bricks per dimension
     int nbricks;
     int per_xcd;       // ceil(nbricks / 8): XCD-contiguous remap of block ids
+    // interior sub-box (bricks whose tile holds no ghost cell): phase-1 launches enumerate only these,
+    // so that every XCD gets an equal share of them
+    int ib_lo[3], ib_n[3];
+    int ib_count, ib_per_xcd;
+    // boundary bricks = the rest, enumerated densely as z-slabs, then y-slabs, then x-slabs (phase 2)
+    int bb_z, bb_y, bb_count, bb_per_xcd;   // bb_z = #bricks in the z-slabs, bb_y = # in the y-slabs
 };
+
+// k-th index of [0, nb) outside the interval [lo, lo + n)
+__host__ __device__ __forceinline__ int outside_interval(int k, int lo, int n) { return k < lo ? k : k + n; }
 
 // tile record in LDS: same bytes as the HBM record (fp64 32 B, fp32 16 B + te plane)
 template <typename real>
@@ -89,6 +98,7 @@ struct BrickArgs {
     size_t pitch;
     real *frc, *en, *vir;
     unsigned long long *stats; // BRICK_STATS: [0] entries, [1] max row, [2] in-cutoff entries
+    int phase;                 // 0: every brick; 1: bricks whose tile has no ghost cell; 2: the others
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -162,10 +172,40 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
     constexpr int BX = Shape::BX, BY = Shape::BY, BZ = Shape::BZ, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC,
                   NOC = Shape::NOC;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int lb = (blockIdx.x % NXCD) * a.bg.per_xcd + blockIdx.x / NXCD;   // XCD-contiguous brick order
-    if (lb >= a.bg.nbricks) return false;
-    bxi = lb % a.bg.nb[0]; byi = (lb / a.bg.nb[0]) % a.bg.nb[1]; bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
     const int Mx = a.g.M[0], My = a.g.M[1], Mz = a.g.M[2];
+    if (a.phase == 1) {
+        // interior bricks only, enumerated densely: the grid is ib_per_xcd * 8 blocks
+        const int li = (blockIdx.x % NXCD) * a.bg.ib_per_xcd + blockIdx.x / NXCD;
+        if (li >= a.bg.ib_count) return false;
+        bxi = a.bg.ib_lo[0] + li % a.bg.ib_n[0];
+        byi = a.bg.ib_lo[1] + (li / a.bg.ib_n[0]) % a.bg.ib_n[1];
+        bzi = a.bg.ib_lo[2] + li / (a.bg.ib_n[0] * a.bg.ib_n[1]);
+    } else if (a.phase == 2) {
+        // boundary bricks only (their tile reaches the outermost cell layer of an open dimension, where
+        // the ghosts of a decomposed run live), enumerated densely
+        int li = (blockIdx.x % NXCD) * a.bg.bb_per_xcd + blockIdx.x / NXCD;
+        if (li >= a.bg.bb_count) return false;
+        const int nx = a.bg.nb[0], ny = a.bg.nb[1];
+        if (li < a.bg.bb_z) {                                   // whole xy planes outside the interior z range
+            bxi = li % nx; byi = (li / nx) % ny;
+            bzi = outside_interval(li / (nx * ny), a.bg.ib_lo[2], a.bg.ib_n[2]);
+        } else if (li < a.bg.bb_z + a.bg.bb_y) {                // interior z, y outside
+            li -= a.bg.bb_z;
+            const int oy = ny - a.bg.ib_n[1];
+            bxi = li % nx; byi = outside_interval((li / nx) % oy, a.bg.ib_lo[1], a.bg.ib_n[1]);
+            bzi = a.bg.ib_lo[2] + li / (nx * oy);
+        } else {                                                // interior z and y, x outside
+            li -= a.bg.bb_z + a.bg.bb_y;
+            const int ox = nx - a.bg.ib_n[0];
+            bxi = outside_interval(li % ox, a.bg.ib_lo[0], a.bg.ib_n[0]);
+            byi = a.bg.ib_lo[1] + (li / ox) % a.bg.ib_n[1];
+            bzi = a.bg.ib_lo[2] + li / (ox * a.bg.ib_n[1]);
+        }
+    } else {
+        const int lb = (blockIdx.x % NXCD) * a.bg.per_xcd + blockIdx.x / NXCD;   // XCD-contiguous brick order
+        if (lb >= a.bg.nbricks) return false;
+        bxi = lb % a.bg.nb[0]; byi = (lb / a.bg.nb[0]) % a.bg.nb[1]; bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
+    }
 
     int my_cnt = 0;
     if (tid < NTC) {

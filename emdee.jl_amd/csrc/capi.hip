@@ -318,11 +318,15 @@ int32_t emdee_md_get_state(emdee_md *md, void *positions_dev, void *velocities_d
 int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every) {
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->step(nsteps, dt, rebuild_every); });
 }
-int32_t emdee_md_kick_drift(emdee_md *md, double dt) {
-    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->kick_drift(dt); });
+int32_t emdee_md_kick_drift(emdee_md *md, double dt, double kick) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->kick_drift(dt, kick); });
 }
-int32_t emdee_md_forces(emdee_md *md, int32_t bitmask) {
-    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->forces(bitmask); });
+int32_t emdee_md_forces(emdee_md *md, int32_t bitmask, int32_t phase) {
+    return guarded([&] {
+        REQUIRE_PTR(md, "md");
+        EMDEE_REQUIRE(phase >= 0 && phase <= 2, EMDEE_ERR_INVALID, "phase must be 0, 1 or 2");
+        md->impl->forces(bitmask, phase);
+    });
 }
 int32_t emdee_md_kick(emdee_md *md, double dt) {
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->kick(dt); });

@@ -28,8 +28,8 @@ struct IMd {
                            const void *inv_mass) = 0;
     virtual void get_state(void *pos, void *vel, void *frc, void *en, void *vir) = 0;
     virtual void step(int nsteps, double dt, int rebuild_every) = 0;
-    virtual void kick_drift(double dt) = 0;
-    virtual void forces(int bitmask) = 0;
+    virtual void kick_drift(double dt, double kick) = 0;
+    virtual void forces(int bitmask, int phase) = 0;
     virtual void kick(double dt) = 0;
     virtual bool needs_rebuild() = 0;
     virtual void rebuild() = 0;

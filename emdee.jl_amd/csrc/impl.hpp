@@ -143,7 +143,7 @@ struct MdImpl : IMd {
     void get_state(void *pos, void *vel, void *frc, void *en, void *vir) override {
         use_device(sys.ctx);
         EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
-        if ((en || vir) && (current_mask & 6) != 6) forces(7);
+        if ((en || vir) && (current_mask & 6) != 6) forces(7, 0);
         sys.unsort((real *)pos, (real *)vel, (real *)frc, (real *)en, (real *)vir);
         EMDEE_HIP_CHECK(hipGetLastError());
     }
@@ -153,7 +153,7 @@ struct MdImpl : IMd {
         EMDEE_REQUIRE(n_ghost == 0, EMDEE_ERR_STATE, "md_step needs n_ghost == 0; decomposed runs drive kick_drift/forces/kick");
         EMDEE_REQUIRE(nsteps >= 0 && dt >= 0, EMDEE_ERR_INVALID, "md_step: negative nsteps or dt");
         if (nsteps == 0) return;
-        if (!(current_mask & EMDEE_FORCES)) forces(EMDEE_FORCES);
+        if (!(current_mask & EMDEE_FORCES)) forces(EMDEE_FORCES, 0);
         for (int s = 0; s < nsteps; s++) {
             // closing half kick of step s-1 fused with the opening half kick of step s: one pass
             sys.kick_drift(s == 0 ? 0.5 * dt : dt, dt);
@@ -166,16 +166,16 @@ struct MdImpl : IMd {
         current_mask = EMDEE_FORCES;
         EMDEE_HIP_CHECK(hipGetLastError());
     }
-    void kick_drift(double dt) override {
+    void kick_drift(double dt, double kick) override {
         use_device(sys.ctx);
-        sys.kick_drift(0.5 * dt, dt);
+        sys.kick_drift(kick * dt, dt);
         since_build++;
         current_mask = 0;
     }
-    void forces(int bitmask) override {
+    void forces(int bitmask, int phase = 0) override {
         use_device(sys.ctx);
-        sys.compute_forces(bitmask);
-        current_mask = bitmask;
+        sys.compute_forces(bitmask, phase);
+        current_mask = phase == 1 ? 0 : bitmask;
         EMDEE_HIP_CHECK(hipGetLastError());
     }
     void kick(double dt) override {
@@ -216,7 +216,7 @@ struct MdImpl : IMd {
     void energies(double out[3]) override {
         use_device(sys.ctx);
         EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
-        if ((current_mask & 7) != 7) forces(7);
+        if ((current_mask & 7) != 7) forces(7, 0);
         sys.energy_sums(0.0, out);
     }
     void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) override {

@@ -49,13 +49,13 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 template <int V>
 struct BrickVariant;
 template <> struct BrickVariant<0> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<1> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 256, G = 16; };
-template <> struct BrickVariant<2> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 16; };
+template <> struct BrickVariant<1> { using Shape = BrickShape<3, 2, 2>; static constexpr int THREADS = 512, G = 8; };
+template <> struct BrickVariant<2> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
 template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 16; };
-template <> struct BrickVariant<4> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 32; };
-template <> struct BrickVariant<5> { using Shape = BrickShape<8, 2, 2>; static constexpr int THREADS = 512, G = 16; };
-template <> struct BrickVariant<6> { using Shape = BrickShape<4, 4, 2>; static constexpr int THREADS = 512, G = 16; };
-template <> struct BrickVariant<7> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
+template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
+template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
+template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8; };
+template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8; };
 
 template <class F>
 static inline void with_brick_variant(int v, F &&f) {
@@ -264,7 +264,7 @@ struct NbSystem {
     }
 
     // ---------------------------------------------------------------- brick plumbing
-    BrickArgs<real> brick_args() {
+    BrickArgs<real> brick_args(int phase = 0) {
         BrickArgs<real> a{};
         a.n = n_total; a.n_owned = n_owned;
         a.rec = rec.ptr; a.te = te.ptr; a.perm = perm.ptr; a.start = start();
@@ -272,6 +272,7 @@ struct NbSystem {
         a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
         a.rlist2 = (real)(rlist * rlist); a.margin = build_margin; a.model = model; a.pitch = pitch;
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
+        a.phase = phase;   // only force launches are phased; build and stats always cover every brick
         return a;
     }
 
@@ -279,7 +280,10 @@ struct NbSystem {
     void launch_brick_kernel() {
         auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM>;
         allow_big_lds(kernel, lds_bytes);
-        hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_bytes, stream(), brick_args());
+        const int phase = MODE == BRICK_FORCE ? force_phase : 0;
+        const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
+        if (blocks == 0) return;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(V::THREADS), lds_bytes, stream(), brick_args(phase));
     }
 
     template <class V>
@@ -312,6 +316,26 @@ struct NbSystem {
             bgrid.nb[2] = (grid.M[2] + S::BZ - 1) / S::BZ;
             bgrid.nbricks = bgrid.nb[0] * bgrid.nb[1] * bgrid.nb[2];
             bgrid.per_xcd = (bgrid.nbricks + NXCD - 1) / NXCD;
+            // interior bricks: along an open dimension, those whose tile (brick +- 1 cell) stays clear of
+            // the outermost cell layers, where the ghosts of a decomposed run live
+            const int B[3] = {S::BX, S::BY, S::BZ};
+            bgrid.ib_count = 1;
+            for (int d = 0; d < 3; d++) {
+                int lo_b = 0, n_b = bgrid.nb[d];
+                if (!grid.per[d]) {
+                    lo_b = 1;
+                    int hi_b = 1;
+                    while (hi_b < bgrid.nb[d] && (hi_b + 1) * B[d] < grid.M[d] - 1) hi_b++;
+                    n_b = std::max(0, hi_b - lo_b);
+                }
+                bgrid.ib_lo[d] = lo_b; bgrid.ib_n[d] = n_b;
+                bgrid.ib_count *= n_b;
+            }
+            bgrid.ib_per_xcd = (bgrid.ib_count + NXCD - 1) / NXCD;
+            bgrid.bb_z = (bgrid.nb[2] - bgrid.ib_n[2]) * bgrid.nb[0] * bgrid.nb[1];
+            bgrid.bb_y = bgrid.ib_n[2] * (bgrid.nb[1] - bgrid.ib_n[1]) * bgrid.nb[0];
+            bgrid.bb_count = bgrid.nbricks - bgrid.ib_count;
+            bgrid.bb_per_xcd = (bgrid.bb_count + NXCD - 1) / NXCD;
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 3, 0, 2 * sizeof(int), stream()));
             hipLaunchKernelGGL((k_brick_tile_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
                                grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], start(),
@@ -398,11 +422,15 @@ struct NbSystem {
                            vir.ptr);
     }
 
-    void compute_forces(int bitmask) {
+    int force_phase = 0;
+
+    void compute_forces(int bitmask, int phase = 0) {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
         EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of 1|2|4");
         if (n_total == 0 || bitmask == 0) return;
+        if (!brick_active && phase == 1) return;   // the direct kernels have no brick phases: all work in phase 2
         Timed t(this, T_FORCE);
+        force_phase = brick_active ? phase : 0;
         if (brick_active) {
             with_brick_variant(variant, [&](auto v) { launch_brick_force<decltype(v)>(bitmask); });
             return;

@@ -183,6 +183,23 @@ class DomainPlan:
     def _exchange_rows(self, send):
         return self._a2a(send, self.send_counts, self.recv_counts)
 
+    def exchange_begin(self, send_buf):
+        """Start the halo exchange without waiting for it.  With the device transport the collective runs
+        on the backend's own stream (it waits for the pack kernel, not for later work), so kernels enqueued
+        afterwards overlap with it; exchange_end makes the current stream wait for the data."""
+        if self.world == 1 or self.transport != "device":
+            return None, self._exchange_rows(send_buf)
+        out = torch.empty((self.n_ghost,) + tuple(send_buf.shape[1:]), dtype=send_buf.dtype, device=send_buf.device)
+        work = dist.all_to_all_single(out, send_buf, output_split_sizes=list(self.recv_counts),
+                                      input_split_sizes=list(self.send_counts), group=self.group, async_op=True)
+        return work, out
+
+    def exchange_end(self, handle):
+        work, out = handle
+        if work is not None:
+            work.wait()
+        return out
+
     def exchange(self, send_buf):
         """The per-step halo exchange: packed positions out, ghost positions in (ordered by source rank,
         matching the ghost slots n_owned .. n_owned + n_ghost - 1)."""
@@ -203,6 +220,9 @@ class DecomposedVerlet:
         self.gid = gid
         self.n_global = None
         self.md = None
+        # overlap the halo exchange with interior bricks (only the device transport runs asynchronously)
+        import os
+        self.overlap = plan.transport == "device" and os.environ.get("EMDEE_DD_OVERLAP", "1") != "0"
         self.since_build = 0
         self._load(x, v, atoms, gid)
 
@@ -231,14 +251,30 @@ class DecomposedVerlet:
         self.since_build = 0
         self._shifts = [c for row in plan.shift_table.tolist() for c in row]
 
-    def _halo(self):
-        plan = self.plan
+    def _forces_with_halo(self):
+        """pack -> exchange (in flight on the collective's stream) || interior bricks -> unpack ->
+        boundary bricks.  Interior = bricks whose LDS tile contains no ghost cell."""
+        plan, F = self.plan, self.pkg.FORCES
         if plan.n_ghost == 0 and plan.send_ids.shape[0] == 0:
+            self.md.forces_(F)
             return
         buf = self.md.pack_positions(plan.send_ids, self._shifts, codes=plan.send_codes)
-        recv = plan.exchange(buf)
+        if not self.overlap:
+            recv = plan.exchange(buf)
+            if plan.n_ghost:
+                self.md.unpack_ghosts_(recv, 0)
+            self.md.forces_(F)
+            return
+        try:
+            handle = plan.exchange_begin(buf)
+        except (RuntimeError, TypeError):          # backend without async all_to_all: exchange in line from now on
+            self.overlap = False
+            handle = (None, plan.exchange(buf))
+        self.md.forces_(F, phase=1)
+        recv = plan.exchange_end(handle)
         if plan.n_ghost:
             self.md.unpack_ghosts_(recv, 0)
+        self.md.forces_(F, phase=2)
 
     def _any_rank(self, flag):
         if self.plan.world == 1:
@@ -254,15 +290,16 @@ class DecomposedVerlet:
         self._load(st["positions"][:n], st["velocities"], self.atoms, self.gid)
 
     def step_(self, nsteps, dt, rebuild_every=0):
-        for _ in range(int(nsteps)):
-            self.md.kick_drift_(dt)
+        for s in range(int(nsteps)):
+            # the closing half kick of step s-1 rides on the opening half kick of step s (same forces)
+            self.md.kick_drift_(dt, 0.5 if s == 0 else 1.0)
             self.since_build += 1
             rb = (self.since_build >= rebuild_every) if rebuild_every > 0 else self._any_rank(self.md.needs_rebuild())
             if rb:
                 self.rebuild_()           # migrates, rebuilds ghosts and lists, evaluates forces
             else:
-                self._halo()
-                self.md.forces_(self.pkg.FORCES)
+                self._forces_with_halo()
+        if int(nsteps) > 0:
             self.md.kick_(dt)
 
     def totals(self):

@@ -55,11 +55,13 @@ class VelocityVerlet:
         _lib.call("emdee_md_step", self._handle, int(nsteps), float(dt), int(rebuild_every))
 
     # -- split step (domain-decomposed driver: kick_drift_ -> halo exchange -> forces_ -> kick_)
-    def kick_drift_(self, dt):
-        _lib.call("emdee_md_kick_drift", self._handle, float(dt))
+    def kick_drift_(self, dt, kick=0.5):
+        """v += kick dt f/m ; x += dt v.  kick = 1.0 fuses the previous step's closing half kick."""
+        _lib.call("emdee_md_kick_drift", self._handle, float(dt), float(kick))
 
-    def forces_(self, bitmask=FORCES):
-        _lib.call("emdee_md_forces", self._handle, int(bitmask))
+    def forces_(self, bitmask=FORCES, phase=0):
+        """phase 0: all; 1: interior bricks (no ghost in their tile); 2: boundary bricks."""
+        _lib.call("emdee_md_forces", self._handle, int(bitmask), int(phase))
 
     def kick_(self, dt):
         _lib.call("emdee_md_kick", self._handle, float(dt))

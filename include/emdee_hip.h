@@ -186,8 +186,12 @@ int32_t emdee_md_get_state(emdee_md *md, void *positions_dev, void *velocities_d
  * rebuild_every > 0: fixed cadence; 0: rebuild when max displacement > skin/2. */
 int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every);
 /* split step for domain-decomposed runs:  kick_drift -> [halo exchange] -> forces -> kick */
-int32_t emdee_md_kick_drift(emdee_md *md, double dt);        /* v += (dt/2m) f ; x += dt v (owned) */
-int32_t emdee_md_forces(emdee_md *md, int32_t bitmask);      /* f (and e, w) of owned atoms */
+/* v += kick (dt/m) f ; x += dt v (owned).  kick = 0.5: the opening half kick; kick = 1.0 also
+ * carries the closing half kick of the previous step (same f), saving one pass over v and f. */
+int32_t emdee_md_kick_drift(emdee_md *md, double dt, double kick);
+/* f (and e, w) of owned atoms.  phase 0: all atoms; phase 1: only bricks whose LDS tile holds no
+ * ghost cell (can run while the halo exchange is in flight); phase 2: the remaining bricks. */
+int32_t emdee_md_forces(emdee_md *md, int32_t bitmask, int32_t phase);
 int32_t emdee_md_kick(emdee_md *md, double dt);              /* v += (dt/2m) f */
 /* 1 if some owned atom moved more than skin/2 since the last build. Blocking. */
 int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag);

@@ -140,11 +140,19 @@ def test_engine_with_ghosts_and_open_boundaries(emdee, oracle):
     assert np.abs(st["forces"].cpu().numpy() - f0[own]).max() < 1e-6 * np.abs(f0).max()
     assert np.abs(st["energies"].cpu().numpy() - e0[own]).max() < 1e-6 * np.abs(e0).max()
     assert np.abs(st["virials"].cpu().numpy() - w0[own]).max() < 1e-6 * np.abs(w0).max()
+    # interior + boundary phases together cover every brick exactly once
+    md.kick_drift_(0.002)                                                  # move the atoms so that stale forces would show
+    md.forces_(E.FORCES, phase=1)
+    md.forces_(E.FORCES, phase=2)
+    f_phases = md.state()["forces"].clone()
+    md.forces_(E.FORCES, phase=0)
+    assert torch.equal(md.state()["forces"], f_phases)
+    assert (f_phases.cpu() - st["forces"].cpu()).abs().max() > 1e-3
     # pack with per-atom image codes, unpack into the ghost slots
     ids = torch.arange(0, 10, dtype=torch.int32, device=dev)
     codes = torch.tensor([0, 1] * 5, dtype=torch.int32, device=dev)
     buf = md.pack_positions(ids, [0.0, 0.0, 0.0, -L, 0.5, 0.0], codes=codes)
-    want = pos[own][:10] + np.where(np.arange(10)[:, None] % 2 == 1, np.array([[-L, 0.5, 0.0]]), 0.0)
+    want = md.state()["positions"].cpu().numpy()[:10] + np.where(np.arange(10)[:, None] % 2 == 1, np.array([[-L, 0.5, 0.0]]), 0.0)
     assert np.abs(buf.cpu().numpy() - want).max() < 1e-12
     new_ghosts = E.cu(gpos + 0.01, dev)
     md.unpack_ghosts_(new_ghosts, 0)
