@@ -285,16 +285,30 @@ __device__ __forceinline__ int brick_locate(const BrickTables<Shape, THREADS> &T
     return oc;
 }
 
-// tile slot s -> tile cell (largest tc with off[tc] <= s)
-template <class Shape, int THREADS>
-__device__ __forceinline__ int brick_cell_of_slot(const BrickTables<Shape, THREADS> &T, int s) {
-    int lo = 0, hi = Shape::NTC;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (T.off[mid] <= s) lo = mid; else hi = mid;
+// Calls f(slot, tile cell) once for every tile slot.  Half-waves take whole tile rows (TX cells,
+// contiguous in the tile and, away from a periodic wrap, in HBM): consecutive lanes touch consecutive
+// records, and a slot's cell is found with TX-1 loop-invariant compares instead of a dependent
+// binary search over all tile cells.
+constexpr int STAGE_LANES = 32;
+template <class Shape, int THREADS, class F>
+__device__ __forceinline__ void brick_for_each_slot(const BrickTables<Shape, THREADS> &T, F &&f) {
+    constexpr int NW = THREADS / STAGE_LANES, NROWS = Shape::TY * Shape::TZ, TX = Shape::TX;
+    const int worker = threadIdx.x / STAGE_LANES, l = threadIdx.x % STAGE_LANES;
+    for (int row = worker; row < NROWS; row += NW) {
+        const int c0 = row * TX;
+        int edge[TX + 1];
+#pragma unroll
+        for (int c = 0; c <= TX; c++) edge[c] = T.off[c0 + c];
+        for (int s = edge[0] + l; s < edge[TX]; s += STAGE_LANES) {
+            int tc = c0;
+#pragma unroll
+            for (int c = 1; c < TX; c++) tc += (edge[c] <= s) ? 1 : 0;
+            f(s, tc);
+        }
     }
-    return lo;
 }
+
+constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetched before the tile is staged
 
 // ------------------------------------------------------------------------------------ build
 template <typename real, class Shape, int THREADS, int G>
@@ -316,8 +330,18 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         org[1] = a.g.lo[1] + (real)(byi * BY) * (a.g.len[1] / (real)a.g.M[1]);
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
-    for (int s = tid; s < tile_n; s += THREADS) {
-        const int tc = brick_cell_of_slot(T, s);
+    // own-atom table entries first (their global loads fly while the tile is being staged)
+    int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS];
+#pragma unroll
+    for (int k = 0; k < OWN_REGS; k++) {
+        const int o = tid + k * THREADS;
+        own_p[k] = own_ti[k] = 0; own_key[k] = 0;
+        if (o < n_own) {
+            brick_locate(T, o, own_ti[k], own_p[k]);
+            own_key[k] = a.perm[own_p[k]];
+        }
+    }
+    brick_for_each_slot(T, [&](int s, int tc) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         const Rec<real> r = a.rec[gp];
@@ -327,8 +351,13 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
         q.w = __int_as_float(gp);
         tile[s] = q;
+    });
+#pragma unroll
+    for (int k = 0; k < OWN_REGS; k++) {
+        const int o = tid + k * THREADS;
+        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
     }
-    for (int o = tid; o < n_own; o += THREADS) {
+    for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         brick_locate(T, o, ti, p);
         T.oinfo[o] = make_int2(p, ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
@@ -411,9 +440,20 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
 
-    // ---- stage the tile: HBM -> LDS, unit stride inside each cell run, image shift applied ------
-    for (int s = tid; s < tile_n; s += THREADS) {
-        const int tc = brick_cell_of_slot(T, s);
+    // ---- own-atom table entries first: their global loads fly while the tile is being staged --------
+    // row length = cnt[p]; the build kernel wrote 0 for ghosts (they own no row and receive no force)
+    int own_p[OWN_REGS], own_ti[OWN_REGS], own_m[OWN_REGS];
+#pragma unroll
+    for (int k = 0; k < OWN_REGS; k++) {
+        const int o = tid + k * THREADS;
+        own_p[k] = own_ti[k] = own_m[k] = 0;
+        if (o < n_own) {
+            brick_locate(T, o, own_ti[k], own_p[k]);
+            own_m[k] = a.cnt[own_p[k]];
+        }
+    }
+    // ---- stage the tile: HBM -> LDS, unit stride inside each tile row, image shift applied -----------
+    brick_for_each_slot(T, [&](int s, int tc) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         Rec<real> r = a.rec[gp];
@@ -422,13 +462,16 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
         tile[s] = r;
         if (sizeof(real) == 4) tile_te[s] = a.te[gp];
+    });
+#pragma unroll
+    for (int k = 0; k < OWN_REGS; k++) {
+        const int o = tid + k * THREADS;
+        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], (own_m[k] << 16) | own_ti[k]);
     }
-    // per own atom: where it lives and its row length (0 for ghosts: they own no row, get no force)
-    for (int o = tid; o < n_own; o += THREADS) {
+    for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         brick_locate(T, o, ti, p);
-        const int m = a.perm[p] < a.n_owned ? a.cnt[p] : 0;
-        T.oinfo[o] = make_int2(p, (m << 16) | ti);
+        T.oinfo[o] = make_int2(p, (a.cnt[p] << 16) | ti);
     }
     __syncthreads();
 

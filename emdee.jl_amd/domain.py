@@ -129,19 +129,23 @@ class DomainPlan:
         return self._a2a(rows, sc, self._counts(sc))
 
     def migrate(self, x, v, atoms, gid):
-        """Re-assign atoms to the bricks that contain them (called at every rebuild).  x (n,3), v (n,3)
-        float64, atoms (n,2) float32, gid (n,) int64 -> the same arrays for the atoms this rank now owns,
-        positions wrapped into the global box, ordered by global id (decomposition-independent order)."""
+        """Re-assign atoms to the bricks that contain them (called at every rebuild).  x (n,3), v (n,3),
+        atoms (n,2) float32, gid (n,) int64 -> the same arrays for the atoms this rank now owns, positions
+        wrapped into the global box.  Only the atoms that left the brick travel (float64 rows: x, v, the two
+        LJAtom floats, the global id); the others keep their order, arrivals are appended."""
         xw = self.wrap(x)
         if self.world > 1:
-            rows = torch.cat([xw.to(torch.float64), v.to(torch.float64), atoms.to(torch.float64),
-                              gid.to(torch.float64).unsqueeze(1)], dim=1)
-            rows = self._all_to_all_rows(rows, self.owner_of(xw))
-            xw, v64, a64, g64 = rows[:, 0:3], rows[:, 3:6], rows[:, 6:8], rows[:, 8]
-            v, atoms, gid = v64.to(v.dtype), a64.to(torch.float32), g64.to(torch.int64)
-            xw = xw.to(x.dtype)
-        order = torch.argsort(gid)
-        return xw[order].contiguous(), v[order].contiguous(), atoms[order].contiguous(), gid[order].contiguous()
+            dest = self.owner_of(xw)
+            leave = dest != self.rank
+            rows = torch.cat([xw[leave].to(torch.float64), v[leave].to(torch.float64), atoms[leave].to(torch.float64),
+                              gid[leave].to(torch.float64).unsqueeze(1)], dim=1)
+            rows = self._all_to_all_rows(rows, dest[leave])
+            stay = ~leave
+            xw = torch.cat([xw[stay], rows[:, 0:3].to(x.dtype)])
+            v = torch.cat([v[stay], rows[:, 3:6].to(v.dtype)])
+            atoms = torch.cat([atoms[stay], rows[:, 6:8].to(torch.float32)])
+            gid = torch.cat([gid[stay], rows[:, 8].to(torch.int64)])
+        return xw.contiguous(), v.contiguous(), atoms.contiguous(), gid.contiguous()
 
     # ------------------------------------------------------------------ ghosts
     def build_ghosts(self, x, atoms):
