@@ -111,8 +111,8 @@ struct BrickTables {
     int *own;      // [NOC+1] prefix of own-cell populations
     int *wtot;     // [NWAVES]
     int2 *oinfo;   // [own_cap] per own atom {cell-order slot p, (row length or flag) << 16 | tile slot}
-    static constexpr size_t fixed_ints() { return (NTC + 4) + NTC + NTC + (NOC + 4) + ((NWAVES + 1) & ~1); }
-    static size_t bytes(int own_cap) { return ((fixed_ints() + 2 * (size_t)own_cap) * 4 + 15) & ~(size_t)15; }
+    __host__ __device__ static constexpr size_t fixed_ints() { return (NTC + 4) + NTC + NTC + (NOC + 4) + ((NWAVES + 1) & ~1); }
+    __host__ __device__ static size_t bytes(int own_cap) { return ((fixed_ints() + 2 * (size_t)own_cap) * 4 + 15) & ~(size_t)15; }
     __device__ __forceinline__ void carve(unsigned char *base) {
         off = reinterpret_cast<int *>(base);
         gbeg = off + (NTC + 4);
@@ -131,8 +131,9 @@ static inline size_t brick_force_lds_bytes(int tile_cap, int own_cap) {
     return tile_bytes + te_bytes + BrickTables<Shape, THREADS>::bytes(own_cap);
 }
 template <class Shape, int THREADS>
-static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap) {
-    return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap);
+static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap, int stride, int G) {
+    // + one row buffer (stride uint16) per G-lane group
+    return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * stride * 2;
 }
 
 // position of the e-th neighbour inside a row: blocks of 8 G entries, lane-major inside a block,
@@ -368,6 +369,14 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;
     const float rl2 = (float)a.rlist2;
     const float lo2 = rl2 - a.margin, hi2 = rl2 + a.margin;   // margin == 0 for fp32 boxes: the fp32 test is exact
+    // Each group assembles its row in LDS (pre-filled with the SENTINEL slot tile_n, a record the force
+    // kernel parks far outside the box, so that it can walk whole blocks with no per-lane bound test) and
+    // writes it out as 16-byte, fully coalesced stores instead of scattered 2-byte ones.
+    unsigned short *rowbuf = reinterpret_cast<unsigned short *>(s_dyn + (size_t)a.tile_cap * 16 +
+                                                                BrickTables<Shape, THREADS>::bytes(a.own_cap)) +
+                             (size_t)gid * a.stride;
+    const unsigned fill2 = (unsigned)tile_n | ((unsigned)tile_n << 16);
+    const uint4 fill = make_uint4(fill2, fill2, fill2, fill2);
     for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
         const int o = ob + gid;
         const bool have = o < n_own;
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
         const float4 qi = tile[ti];
         unsigned short *row = a.nbr + (size_t)p * a.stride;
+        for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
         int count = 0;
 #pragma unroll 1
         for (int dz = -1; dz <= 1; dz++) {
@@ -408,15 +418,19 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     const unsigned long long bits = group_bits<G>(__ballot(pass), lane);
                     if (pass) {
                         const int e = count + __popcll(bits & ((1ull << gl) - 1ull));
-                        if (e < a.stride) row[row_position<G>(e)] = (unsigned short)c;
+                        if (e < a.stride) rowbuf[row_position<G>(e)] = (unsigned short)c;
                     }
                     count += __popcll(bits);
                 }
             }
         }
-        if (have && gl == 0) {
-            a.cnt[p] = act ? min(count, a.stride) : 0;
-            if (count > a.stride) atomicMax(&a.flags[0], count);
+        if (have) {
+            for (int c = gl * EPL; c < a.stride; c += G * EPL)
+                *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
+            if (gl == 0) {
+                a.cnt[p] = act ? min(count, a.stride) : 0;
+                if (count > a.stride) atomicMax(&a.flags[0], count);
+            }
         }
     }
 }
@@ -463,6 +477,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         tile[s] = r;
         if (sizeof(real) == 4) tile_te[s] = a.te[gp];
     });
+    if (tid == 0) {   // the sentinel record every unused row entry points at: fails r2 < rc2, never NaN
+        Rec<real> far;
+        const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
+        far.x = far.y = far.z = big; far.hs = 0;
+        tile[tile_n] = far;
+        if (sizeof(real) == 4) tile_te[tile_n] = 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
@@ -511,15 +532,15 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         auto block = [&](const uint4 &q, int b0) {
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
-                if (b0 + t * G >= wm) break;                  // wave-uniform
-                if (b0 + t * G + gl < m) {
+                if (b0 + t * G >= wm) break;                  // wave-uniform; entries past a row's end are sentinels
+                {
                     const int sj = pick16(q, t);
                     real xj, yj, zj, hs_j, te_j;
                     tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
                     const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const real r2 = dx * dx + dy * dy + dz * dz;
                     if (MODE == BRICK_STATS) {
-                        st_inside += (r2 < a.model.rc2) ? 1ull : 0ull;
+                        st_inside += (b0 + t * G + gl < m && r2 < a.model.rc2) ? 1ull : 0ull;
                     } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
                         real E, W;

@@ -18,6 +18,7 @@ struct LJModel {
     real rc2, rs2, idl2;
     real x0;      // rs2 * idl2
     real c60;     // 60 * idl2
+    real k3, k6;  // 3 and 6 as kernel arguments: SGPR operands instead of per-iteration literal moves
 };
 
 template <typename real>
@@ -27,14 +28,15 @@ static inline LJModel<real> make_model(const emdee_lj_model &m) {
     r.rc2 = (real)m.rc2; r.rs2 = (real)m.rs2; r.idl2 = (real)m.inv_delta2;
     r.x0 = r.rs2 * r.idl2;
     r.c60 = (real)60 * r.idl2;
+    r.k3 = (real)3; r.k6 = (real)6;
     return r;
 }
 
 __device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }   // v_rcp_f32, 1 ulp
 __device__ __forceinline__ double fast_rcp(double a) {
-    // v_rcp_f64 seed + two Newton steps: full fp64 accuracy without the IEEE division sequence
+    // v_rcp_f64 seed (measured on gfx950: 4.5e-8 relative) + one Newton step -> 2.2e-15 relative
+    // (profiles/README.md), without the ~12-instruction IEEE division sequence
     double r = __builtin_amdgcn_rcp(a);
-    r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
     return r;
 }
@@ -63,10 +65,11 @@ __device__ __forceinline__ void lj_interaction(real r2, real inv_r2, const LJMod
     const real W = (real)6 * (E + t);                                  // :35  24 eps (2 s^-12 - s^-6)
     const real x = switch_clamp(r2 * m.idl2 - m.x0);                   // :36-37
     const real x2 = x * x;                                             // :38
-    const real q = (real)15 * x - (real)10 - (real)6 * x2;             // :39  g = 1 + x^3 (15 x - 6 x^2 - 10)
-    const real g = (real)1 + x2 * x * q;
-    const real u = (real)1 - x;                                        // :40  1 - 2x + x^2 = (1-x)^2
-    const real mgr = m.c60 * (x2 * (u * u)) * r2;                      //      -r g' = 60 x^2 (1-x)^2 idl2 r2
+    // :39  g = 1 + x^3 (15 x - 6 x^2 - 10) = (1-x)^3 (1 + 3x + 6x^2)   (same quintic, shares u = 1-x with g')
+    const real u = (real)1 - x;
+    const real u2 = u * u;
+    const real g = (u2 * u) * ((real)1 + x * (m.k3 + m.k6 * x));
+    const real mgr = m.c60 * (x2 * u2) * r2;                           // :40  -r g' = 60 x^2 (1-x)^2 idl2 r2
     E_out = E * g;                                                     // :41
     W_out = W * g + E * mgr;
 }

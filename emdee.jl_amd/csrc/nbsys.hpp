@@ -103,6 +103,7 @@ struct NbSystem {
     BrickGrid bgrid{};
     int tile_cap = 0, own_cap = 0, row_block = 1;
     size_t lds_bytes = 0, lds_build_bytes = 0;
+    int build_variant_threads = 0, build_variant_g = 0;
     float build_margin = 0.f;
 
     DevBuf<Rec<real>> rec, rec2;
@@ -271,6 +272,7 @@ struct NbSystem {
         a.g = grid; a.bg = bgrid; a.tile_cap = tile_cap; a.own_cap = own_cap;
         a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
         a.rlist2 = (real)(rlist * rlist); a.margin = build_margin; a.model = model; a.pitch = pitch;
+        if (const char *dbg = std::getenv("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
         return a;
@@ -342,10 +344,10 @@ struct NbSystem {
                                flags.ptr + 3);
             EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 3, flags.ptr + 3, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
-            tile_cap = std::max(64, (ctx->host_flags[3] + 15) / 16 * 16);
+            tile_cap = std::max(64, (ctx->host_flags[3] + 1 + 15) / 16 * 16);   // + 1: the sentinel record
             own_cap = std::max(64, (ctx->host_flags[4] + 15) / 16 * 16);
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
-            lds_build_bytes = brick_build_lds_bytes<S, V::THREADS>(tile_cap, own_cap);
+            build_variant_threads = V::THREADS; build_variant_g = V::G;
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
             // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
@@ -383,6 +385,7 @@ struct NbSystem {
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
                     auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G>;
+                    lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::G);
                     allow_big_lds(kernel, lds_build_bytes);
                     hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(),
                                        brick_args());
