@@ -33,7 +33,11 @@
 
 namespace emdee {
 
-enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2 };
+// BRICK_STEP = the force pass with the velocity-Verlet update fused in: the owner lane of each atom adds
+// v += c f / m, x += dt v straight from its registers and writes the NEXT position buffer (positions are
+// ping-ponged, other workgroups are still staging the current ones), so an inner MD step is one kernel:
+// no separate kick/drift pass and no force array round trip.
+enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2, BRICK_STEP = 3 };
 
 constexpr int EPL = 8;   // neighbour entries per lane per 16-byte load
 
@@ -99,6 +103,13 @@ struct BrickArgs {
     real *frc, *en, *vir;
     unsigned long long *stats; // BRICK_STATS: [0] entries, [1] max row, [2] in-cutoff entries
     int phase;                 // 0: every brick; 1: bricks whose tile has no ghost cell; 2: the others
+    // BRICK_STEP only
+    real *vel;                 // SoA planes, updated in place
+    const real *xb;            // positions at the last build (rebuild trigger)
+    const real *inv_mass;      // may be NULL
+    Rec<real> *rec_next;       // position buffer of the next step
+    real kick_c, dt, thr2;
+    int *trigger;
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -528,6 +539,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         real xi, yi, zi, hs_i, te_i;
         tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
+        real vx = 0, vy = 0, vz = 0, bx = 0, by = 0, bz = 0, imv = 1;
+        if (MODE == BRICK_STEP && have && gl == G - 1) {      // owner lane: its loads fly during the pair loop
+            vx = a.vel[p]; vy = a.vel[a.pitch + p]; vz = a.vel[2 * a.pitch + p];
+            bx = a.xb[p]; by = a.xb[a.pitch + p]; bz = a.xb[2 * a.pitch + p];
+            if (a.inv_mass) imv = a.inv_mass[p];
+        }
         // one block of 8 G neighbours: lane gl holds entries b0 + gl + t G, t = 0..7, in q
         auto block = [&](const uint4 &q, int b0) {
 #pragma unroll
@@ -572,7 +589,18 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             }
             if (BITMASK & EMDEE_ENERGIES) e = group_sum_to_last<G>(e);
             if (BITMASK & EMDEE_VIRIALS) w = group_sum_to_last<G>(w);
-            if (have && gl == G - 1) {
+            if (MODE == BRICK_STEP) {
+                if (have && gl == G - 1) {
+                    const real cm = a.kick_c * imv;
+                    vx += cm * fx; vy += cm * fy; vz += cm * fz;
+                    a.vel[p] = vx; a.vel[a.pitch + p] = vy; a.vel[2 * a.pitch + p] = vz;
+                    Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
+                    r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz;
+                    a.rec_next[p] = r;
+                    const real ex = r.x - bx, ey = r.y - by, ez = r.z - bz;
+                    if (ex * ex + ey * ey + ez * ez > a.thr2) *a.trigger = 1;
+                }
+            } else if (have && gl == G - 1) {
                 if (BITMASK & EMDEE_FORCES) {
                     a.frc[p] = fx; a.frc[a.pitch + p] = fy; a.frc[2 * a.pitch + p] = fz;
                 }

@@ -154,13 +154,20 @@ struct MdImpl : IMd {
         EMDEE_REQUIRE(nsteps >= 0 && dt >= 0, EMDEE_ERR_INVALID, "md_step: negative nsteps or dt");
         if (nsteps == 0) return;
         if (!(current_mask & EMDEE_FORCES)) forces(EMDEE_FORCES, 0);
-        for (int s = 0; s < nsteps; s++) {
-            // closing half kick of step s-1 fused with the opening half kick of step s: one pass
-            sys.kick_drift(s == 0 ? 0.5 * dt : dt, dt);
+        // x_1 = x_0 + dt (v_0 + dt/2 f_0); then every inner step is ONE kernel (force + full kick + drift:
+        // the closing half kick of step s rides on the opening half kick of step s+1); the last step ends
+        // with a plain force pass and the closing half kick.
+        sys.kick_drift(0.5 * dt, dt);
+        for (int s = 1; s <= nsteps; s++) {
             since_build++;
             bool rb = rebuild_every > 0 ? since_build >= rebuild_every : sys.read_rebuild_flag();
             if (rb) { sys.resort(); since_build = 0; }
-            sys.compute_forces(EMDEE_FORCES);
+            if (s == nsteps) {
+                sys.compute_forces(EMDEE_FORCES);
+            } else if (!sys.fused_step(dt, dt)) {
+                sys.compute_forces(EMDEE_FORCES);
+                sys.kick_drift(dt, dt);
+            }
         }
         sys.kick(0.5 * dt);
         current_mask = EMDEE_FORCES;

@@ -275,6 +275,9 @@ struct NbSystem {
         if (const char *dbg = std::getenv("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
+        a.vel = vel.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
+        a.kick_c = (real)step_c; a.dt = (real)step_dt;
+        a.thr2 = (real)(0.25 * skin * skin); a.trigger = flags.ptr + 1;
         return a;
     }
 
@@ -426,6 +429,20 @@ struct NbSystem {
     }
 
     int force_phase = 0;
+    double step_c = 0.0, step_dt = 0.0;
+
+    // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
+    // the other position buffer.  False if the brick kernels are not in use (caller runs the split kernels).
+    bool fused_step(double c, double dt) {
+        EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
+        if (!brick_active || n_total == 0) return false;
+        Timed t(this, T_FORCE);
+        step_c = c; step_dt = dt;
+        force_phase = 0;
+        with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
+        rec.swap(rec2);
+        return true;
+    }
 
     void compute_forces(int bitmask, int phase = 0) {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
