@@ -150,10 +150,9 @@ static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap, int stride
 // position of the e-th neighbour inside a row: blocks of 8 G entries, lane-major inside a block,
 // so lane l of the group finds entries l, l+G, ..., l+7G of the block in 8 consecutive uint16
 template <int G>
-__host__ __device__ __forceinline__ int row_position(int e) {
-    constexpr int BLK = EPL * G;
-    const int blk = e / BLK, r = e % BLK;
-    return blk * BLK + (r % G) * EPL + (r / G);
+__host__ __device__ __forceinline__ unsigned row_position(unsigned e) {
+    constexpr unsigned BLK = EPL * G;   // all powers of two: three masks/shifts
+    return (e & ~(BLK - 1u)) | ((e & (G - 1u)) * EPL) | ((e / G) & (EPL - 1u));
 }
 
 template <int G>
@@ -386,6 +385,13 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     unsigned short *rowbuf = reinterpret_cast<unsigned short *>(s_dyn + (size_t)a.tile_cap * 16 +
                                                                 BrickTables<Shape, THREADS>::bytes(a.own_cap)) +
                              (size_t)gid * a.stride;
+    // ballot bits of my group, in 32-bit arithmetic (a group never straddles the two halves of the mask)
+    static_assert(G <= 32, "build kernel: groups of at most 32 lanes");
+    const unsigned gshift = (unsigned)(lane & 31 & ~(G - 1));
+    const unsigned gmask = G == 32 ? 0xffffffffu : ((1u << G) - 1u);
+    const unsigned ltmask = (1u << gl) - 1u;
+    const bool upper = lane >= 32;
+    const unsigned ustride = (unsigned)a.stride;
     const unsigned fill2 = (unsigned)tile_n | ((unsigned)tile_n << 16);
     const uint4 fill = make_uint4(fill2, fill2, fill2, fill2);
     for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         const float4 qi = tile[ti];
         unsigned short *row = a.nbr + (size_t)p * a.stride;
         for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
-        int count = 0;
+        unsigned count = 0;
 #pragma unroll 1
         for (int dz = -1; dz <= 1; dz++) {
 #pragma unroll 1
@@ -426,12 +432,14 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                             pass = ex * ex + ey * ey + ez * ez < a.rlist2;
                         }
                     }
-                    const unsigned long long bits = group_bits<G>(__ballot(pass), lane);
+                    const unsigned long long mask = __ballot(pass);
+                    const unsigned half = upper ? (unsigned)(mask >> 32) : (unsigned)mask;
+                    const unsigned bits = (half >> gshift) & gmask;
                     if (pass) {
-                        const int e = count + __popcll(bits & ((1ull << gl) - 1ull));
-                        if (e < a.stride) rowbuf[row_position<G>(e)] = (unsigned short)c;
+                        const unsigned e = count + __popc(bits & ltmask);
+                        if (e < ustride) rowbuf[row_position<G>(e)] = (unsigned short)c;
                     }
-                    count += __popcll(bits);
+                    count += __popc(bits);
                 }
             }
         }
@@ -439,8 +447,8 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
             for (int c = gl * EPL; c < a.stride; c += G * EPL)
                 *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
             if (gl == 0) {
-                a.cnt[p] = act ? min(count, a.stride) : 0;
-                if (count > a.stride) atomicMax(&a.flags[0], count);
+                a.cnt[p] = act ? (int)min(count, ustride) : 0;
+                if (count > ustride) atomicMax(&a.flags[0], (int)count);
             }
         }
     }
