@@ -515,6 +515,11 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     }
     __syncthreads();
 
+    // Loop-invariant operands that would otherwise be re-materialised from SGPRs inside every pair
+    // iteration (a VOP3 instruction takes one scalar source): keep them in VGPRs.
+    LJModel<real> mdl = a.model;
+    asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
+
     // ---- own atoms: one G-lane group per atom; the NEXT atom's indices are fetched meanwhile -----
     const int gl = lane & (G - 1);                            // lane inside the group
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;     // group inside the block
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
                         real E, W;
-                        lj_interaction(r2, inv_r2, a.model, hs_i, te_i, hs_j, te_j, E, W);
+                        lj_interaction(r2, inv_r2, mdl, hs_i, te_i, hs_j, te_j, E, W);
                         if (BITMASK & EMDEE_FORCES) {
                             const real wr2 = W * inv_r2;      // src/nonbonded.jl:139
                             fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;

@@ -50,9 +50,9 @@ template <int V>
 struct BrickVariant;
 template <> struct BrickVariant<0> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 8; };
 template <> struct BrickVariant<1> { using Shape = BrickShape<3, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<2> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
+template <> struct BrickVariant<2> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 512, G = 8; };
 template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 16; };
-template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
+template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 512, G = 8; };
 template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
 template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8; };
 template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8; };

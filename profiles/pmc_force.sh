@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("%s/%s_p*/*/*_counter_collection.csv" % (root, tag)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_brick<" in k and ", 1, 1>" in k:
+        if "k_brick<" in k and (", 1, 1>" in k or ", 3, 1>" in k):
             agg["force"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, v in sorted(agg["force"].items()):
     print("%-28s %16.0f  (avg of %d launches)" % (name, sum(v) / len(v), len(v)))
