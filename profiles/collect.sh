@@ -1,0 +1,12 @@
+#!/bin/bash
+# Produces the evidence kept under profiles/<round>/ : the default bench line, the rocprofv3 kernel
+# statistics of the same command, and the HBM traffic of the dominant kernel from PMC counters
+# (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes).
+# Usage (on the GPU box, from the repository root):  bash profiles/collect.sh r01
+TAG=${1:-r01}; R=$PWD; OUT=$R/gpurun_out/collect_$TAG; mkdir -p $OUT
+timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "bench failed"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1 || echo "stats failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || echo "fetch failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || echo "write failed"
+cd $R && python3 profiles/summarize.py $OUT $TAG
