@@ -69,6 +69,7 @@ SIGNATURES = {
     "emdee_md_kick_drift": [_p, _dbl, _dbl],
     "emdee_md_forces": [_p, _i32, _i32],
     "emdee_md_kick": [_p, _dbl],
+    "emdee_md_fused_step": [_p, _dbl, _dbl, _i32, C.POINTER(_i32)],
     "emdee_md_needs_rebuild": [_p, C.POINTER(_i32)],
     "emdee_md_rebuild": [_p],
     "emdee_md_pack_positions": [_p, _p, _p, _i32, _d3, _i32, _p],

@@ -331,6 +331,14 @@ int32_t emdee_md_forces(emdee_md *md, int32_t bitmask, int32_t phase) {
 int32_t emdee_md_kick(emdee_md *md, double dt) {
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->kick(dt); });
 }
+int32_t emdee_md_fused_step(emdee_md *md, double dt, double kick, int32_t phase, int32_t *fused) {
+    return guarded([&] {
+        REQUIRE_PTR(md, "md");
+        EMDEE_REQUIRE(phase >= 0 && phase <= 2, EMDEE_ERR_INVALID, "phase must be 0, 1 or 2");
+        const bool ok = md->impl->fused_step(dt, kick, phase);
+        if (fused) *fused = ok ? 1 : 0;
+    });
+}
 int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag) {
     return guarded([&] { REQUIRE_PTR(md, "md"); REQUIRE_PTR(flag, "flag"); *flag = md->impl->needs_rebuild() ? 1 : 0; });
 }

@@ -31,6 +31,7 @@ struct IMd {
     virtual void kick_drift(double dt, double kick) = 0;
     virtual void forces(int bitmask, int phase) = 0;
     virtual void kick(double dt) = 0;
+    virtual bool fused_step(double dt, double kick, int phase) = 0;
     virtual bool needs_rebuild() = 0;
     virtual void rebuild() = 0;
     virtual void pack_positions(const int32_t *ids, const int32_t *codes, int n, const double *shifts, int n_shifts,

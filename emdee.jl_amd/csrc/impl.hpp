@@ -164,7 +164,7 @@ struct MdImpl : IMd {
             if (rb) { sys.resort(); since_build = 0; }
             if (s == nsteps) {
                 sys.compute_forces(EMDEE_FORCES);
-            } else if (!sys.fused_step(dt, dt)) {
+            } else if (!sys.fused_step(dt, dt, 0)) {
                 sys.compute_forces(EMDEE_FORCES);
                 sys.kick_drift(dt, dt);
             }
@@ -188,6 +188,13 @@ struct MdImpl : IMd {
     void kick(double dt) override {
         use_device(sys.ctx);
         sys.kick(0.5 * dt);
+    }
+    bool fused_step(double dt, double kick, int phase) override {
+        use_device(sys.ctx);
+        const bool ok = sys.fused_step(kick * dt, dt, phase);
+        if (ok) { since_build += (phase != 1) ? 1 : 0; current_mask = 0; }
+        EMDEE_HIP_CHECK(hipGetLastError());
+        return ok;
     }
     bool needs_rebuild() override {
         use_device(sys.ctx);

@@ -580,6 +580,14 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, 
     if (vir_out) vir_out[i] = vir[p];
 }
 
+// fused decomposed step: ghost records (not owned, never integrated here) follow the buffer swap
+template <typename real>
+__global__ void k_copy_ghost_records(int n, int n_owned, const int *__restrict__ perm, const Rec<real> *__restrict__ src,
+                                     Rec<real> *__restrict__ dst) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && perm[p] >= n_owned) dst[p] = src[p];
+}
+
 // halo exchange helpers: gather positions (+ periodic shift) of listed caller ids;
 // scatter received positions into ghost records
 template <typename real>

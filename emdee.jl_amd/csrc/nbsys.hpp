@@ -12,7 +12,7 @@
 
 namespace emdee {
 
-enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_COUNT = 4 };
+enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_STEP = 4, T_COUNT = 5 };
 enum PathId { PATH_BRICK = 0, PATH_DIRECT = 1 };
 
 // in-place exclusive scan of int32 data[0..n) (n may exceed one tile: recursive tile sums)
@@ -285,7 +285,7 @@ struct NbSystem {
     void launch_brick_kernel() {
         auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM>;
         allow_big_lds(kernel, lds_bytes);
-        const int phase = MODE == BRICK_FORCE ? force_phase : 0;
+        const int phase = (MODE == BRICK_FORCE || MODE == BRICK_STEP) ? force_phase : 0;
         const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
         if (blocks == 0) return;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(V::THREADS), lds_bytes, stream(), brick_args(phase));
@@ -433,14 +433,21 @@ struct NbSystem {
 
     // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
     // the other position buffer.  False if the brick kernels are not in use (caller runs the split kernels).
-    bool fused_step(double c, double dt) {
+    bool fused_step(double c, double dt, int phase = 0) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         if (!brick_active || n_total == 0) return false;
-        Timed t(this, T_FORCE);
+        Timed t(this, T_STEP);
         step_c = c; step_dt = dt;
-        force_phase = 0;
+        force_phase = phase;
         with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
-        rec.swap(rec2);
+        // Ghost records are never written by the step kernel: carry their current image over so that the
+        // buffer that becomes current next is complete even before the next halo unpack.
+        if (phase != 1) {
+            if (n_total > n_owned)
+                hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(),
+                                   n_total, n_owned, perm.ptr, rec.ptr, rec2.ptr);
+            rec.swap(rec2);
+        }
         return true;
     }
 

@@ -227,6 +227,7 @@ class DecomposedVerlet:
         # overlap the halo exchange with interior bricks (only the device transport runs asynchronously)
         import os
         self.overlap = plan.transport == "device" and os.environ.get("EMDEE_DD_OVERLAP", "1") != "0"
+        self.fused = os.environ.get("EMDEE_DD_FUSED", "1") != "0"
         self.since_build = 0
         self._load(x, v, atoms, gid)
 
@@ -255,30 +256,50 @@ class DecomposedVerlet:
         self.since_build = 0
         self._shifts = [c for row in plan.shift_table.tolist() for c in row]
 
-    def _forces_with_halo(self):
-        """pack -> exchange (in flight on the collective's stream) || interior bricks -> unpack ->
-        boundary bricks.  Interior = bricks whose LDS tile contains no ghost cell."""
-        plan, F = self.plan, self.pkg.FORCES
+    def _with_halo(self, compute):
+        """The per-step pattern: pack -> exchange (in flight on the collective's stream) || compute(phase 1:
+        interior bricks, whose LDS tile holds no ghost cell) -> unpack -> compute(phase 2: boundary bricks).
+        Without ghosts, or when the transport cannot run asynchronously, one compute(phase 0)."""
+        plan = self.plan
         if plan.n_ghost == 0 and plan.send_ids.shape[0] == 0:
-            self.md.forces_(F)
-            return
+            return compute(0)
         buf = self.md.pack_positions(plan.send_ids, self._shifts, codes=plan.send_codes)
         if not self.overlap:
             recv = plan.exchange(buf)
             if plan.n_ghost:
                 self.md.unpack_ghosts_(recv, 0)
-            self.md.forces_(F)
-            return
+            return compute(0)
         try:
             handle = plan.exchange_begin(buf)
         except (RuntimeError, TypeError):          # backend without async all_to_all: exchange in line from now on
             self.overlap = False
             handle = (None, plan.exchange(buf))
-        self.md.forces_(F, phase=1)
+        compute(1)
         recv = plan.exchange_end(handle)
         if plan.n_ghost:
             self.md.unpack_ghosts_(recv, 0)
-        self.md.forces_(F, phase=2)
+        return compute(2)
+
+    def _forces_with_halo(self):
+        self._with_halo(lambda phase: self.md.forces_(self.pkg.FORCES, phase=phase))
+
+    def _fused_step_with_halo(self, dt):
+        """One inner step: forces at the current positions (ghosts refreshed on the way) with the full kick
+        and the drift fused into the same kernel.  Falls back to the split kernels if the engine declines."""
+        if self.fused:
+            state = {"ok": True}
+
+            def compute(phase):
+                if state["ok"] and not self.md.fused_step_(dt, 1.0, phase=phase):
+                    state["ok"] = False
+                if not state["ok"] and phase != 1:          # engine has no tiled kernels for this box
+                    self.md.forces_(self.pkg.FORCES)
+                    self.md.kick_drift_(dt, 1.0)
+            self._with_halo(compute)
+            self.fused = state["ok"]
+        else:
+            self._forces_with_halo()
+            self.md.kick_drift_(dt, 1.0)
 
     def _any_rank(self, flag):
         if self.plan.world == 1:
@@ -294,17 +315,25 @@ class DecomposedVerlet:
         self._load(st["positions"][:n], st["velocities"], self.atoms, self.gid)
 
     def step_(self, nsteps, dt, rebuild_every=0):
-        for s in range(int(nsteps)):
-            # the closing half kick of step s-1 rides on the opening half kick of step s (same forces)
-            self.md.kick_drift_(dt, 0.5 if s == 0 else 1.0)
+        """nsteps velocity-Verlet steps.  x_1 = x_0 + dt (v_0 + dt/2 f_0); every inner step is then one fused
+        kernel pass (force + full kick + drift: the closing half kick of a step rides on the opening half kick
+        of the next); the last step ends with a plain force pass and the closing half kick."""
+        nsteps = int(nsteps)
+        if nsteps <= 0:
+            return
+        self.md.kick_drift_(dt, 0.5)
+        for s in range(1, nsteps + 1):
             self.since_build += 1
             rb = (self.since_build >= rebuild_every) if rebuild_every > 0 else self._any_rank(self.md.needs_rebuild())
             if rb:
-                self.rebuild_()           # migrates, rebuilds ghosts and lists, evaluates forces
-            else:
+                self.rebuild_()                   # migrates, rebuilds ghosts and lists, evaluates forces
+                if s < nsteps:
+                    self.md.kick_drift_(dt, 1.0)
+            elif s == nsteps:
                 self._forces_with_halo()
-        if int(nsteps) > 0:
-            self.md.kick_(dt)
+            else:
+                self._fused_step_with_halo(dt)
+        self.md.kick_(dt)
 
     def totals(self):
         """Global (potential, kinetic, virial) sums."""

@@ -8,7 +8,7 @@ from . import _lib
 from .device import check_array, context_for, precision_of
 from .nonbonded import ENERGIES, FORCES, VIRIALS
 
-KERNELS = {"lj_force_nbr": 0, "verlet_kick_drift": 1, "rebuild": 2, "verlet_kick": 3}
+KERNELS = {"lj_force_nbr": 0, "verlet_kick_drift": 1, "rebuild": 2, "verlet_kick": 3, "lj_force_nbr_fused_step": 4}
 
 
 class VelocityVerlet:
@@ -65,6 +65,13 @@ class VelocityVerlet:
 
     def kick_(self, dt):
         _lib.call("emdee_md_kick", self._handle, float(dt))
+
+    def fused_step_(self, dt, kick=1.0, phase=0):
+        """One inner step as one kernel (force + kick + drift, positions ping-ponged).  Returns False, having
+        done nothing, when the LDS-tiled kernels are not in use for this box."""
+        ok = C.c_int32(0)
+        _lib.call("emdee_md_fused_step", self._handle, float(dt), float(kick), int(phase), C.byref(ok))
+        return bool(ok.value)
 
     def needs_rebuild(self):
         f = C.c_int32()

@@ -193,6 +193,12 @@ int32_t emdee_md_kick_drift(emdee_md *md, double dt, double kick);
  * ghost cell (can run while the halo exchange is in flight); phase 2: the remaining bricks. */
 int32_t emdee_md_forces(emdee_md *md, int32_t bitmask, int32_t phase);
 int32_t emdee_md_kick(emdee_md *md, double dt);              /* v += (dt/2m) f */
+/* One inner step as a single kernel: f = F(x), v += kick (dt/m) f, x += dt v, with the new positions
+ * written to the second position buffer.  phase as in emdee_md_forces; the buffers are swapped after
+ * phase 0 or phase 2, so a decomposed run calls phase 1 (interior bricks, while the halo exchange of
+ * the CURRENT positions is in flight), unpacks the ghosts, then phase 2.  Sets *fused = 0 and does
+ * nothing if the LDS-tiled kernels are not in use for this box (caller falls back to the split step). */
+int32_t emdee_md_fused_step(emdee_md *md, double dt, double kick, int32_t phase, int32_t *fused);
 /* 1 if some owned atom moved more than skin/2 since the last build. Blocking. */
 int32_t emdee_md_needs_rebuild(emdee_md *md, int32_t *flag);
 /* re-bin, re-sort and rebuild the neighbour list from the current positions */
@@ -211,8 +217,9 @@ int32_t emdee_md_nbr_stats(emdee_md *md, int64_t *builds, int64_t *listed, int32
                            int32_t *capacity);
 int32_t emdee_md_count_pairs(emdee_md *md, int64_t *pairs_in_cutoff);
 /* Per-kernel device time from HIP events recorded on the context's stream while
- * profiling is on.  kernel: 0 = lj_force_nbr, 1 = verlet_kick_drift, 2 = rebuild
- * (bin + sort + nbr_build), 3 = verlet_kick.  Blocking. */
+ * profiling is on.  kernel: 0 = lj_force_nbr (plain force launches), 1 = verlet_kick_drift, 2 = rebuild
+ * (bin + sort + nbr_build), 3 = verlet_kick, 4 = lj_force_nbr with the velocity-Verlet update fused in
+ * (emdee_md_step's inner steps, emdee_md_fused_step).  Blocking. */
 int32_t emdee_md_profile(emdee_md *md, int32_t enable);
 int32_t emdee_md_kernel_time(emdee_md *md, int32_t kernel, double *total_ms, int64_t *launches);
 

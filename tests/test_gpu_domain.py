@@ -42,7 +42,7 @@ def _global_box(syn):
     return pos, vel, eps, sigma, float(lengths[0])
 
 
-def _worker(rank, world, port, out_dir, nsteps, rebuild_every):
+def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -64,6 +64,7 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every):
         dd = domain.DecomposedVerlet(pkg, plan, pkg.cu(pos[mine], dev), pkg.cu(vel[mine], dev), pkg.cu(atoms[mine], dev),
                                      torch.from_numpy(mine).to(dev), model, skin=SKIN)
         assert plan.n_ghost > 0
+        dd.overlap = bool(phased)      # interior / boundary phases (here around a synchronous, host-staged exchange)
         e0 = dd.totals()
         dd.step_(nsteps, DT, rebuild_every)
         e1 = dd.totals()
@@ -74,10 +75,10 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rebuild_every", [(2, 0), (2, 4), (4, 0)])
-def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every):
+@pytest.mark.parametrize("world,rebuild_every,phased", [(2, 0, 0), (2, 4, 1), (4, 0, 1), (2, 7, 1)])
+def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every, phased):
     nsteps = 25
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every, phased), nprocs=world, join=True)
     pos, vel, eps, sigma, L = _global_box(emdee.synthetic)
     N = pos.shape[0]
     ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, nsteps)
