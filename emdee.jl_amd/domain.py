@@ -151,18 +151,30 @@ class DomainPlan:
     def build_ghosts(self, x, atoms):
         """Choose the owned atoms every neighbour needs as ghosts, exchange them, and remember the send
         lists for the per-step position exchange.  Returns (ghost positions, ghost atoms)."""
-        n = x.shape[0]
         dev = x.device
         ids_per_rank = [[] for _ in range(self.world)]
         codes_per_rank = [[] for _ in range(self.world)]
+        # one pass per cut dimension over all atoms, then the 26 directions only over the shell atoms
+        near_lo, near_hi = {}, {}
+        shell = None
+        for d in range(3):
+            if self.cut[d]:
+                near_lo[d] = x[:, d] < self.lo[d] + self.halo
+                near_hi[d] = x[:, d] >= self.hi[d] - self.halo
+                either = near_lo[d] | near_hi[d]
+                shell = either if shell is None else (shell | either)
+        if shell is not None:
+            sidx = torch.nonzero(shell, as_tuple=False).squeeze(1)
+            lo_s = {d: near_lo[d][sidx] for d in near_lo}
+            hi_s = {d: near_hi[d][sidx] for d in near_hi}
+            sidx32 = sidx.to(torch.int32)
         for k, s in enumerate(self.dirs):
-            mask = torch.ones(n, dtype=torch.bool, device=dev)
+            mask = None
             for d in range(3):
-                if s[d] > 0:
-                    mask &= x[:, d] >= self.hi[d] - self.halo
-                elif s[d] < 0:
-                    mask &= x[:, d] < self.lo[d] + self.halo
-            ids = torch.nonzero(mask, as_tuple=False).squeeze(1).to(torch.int32)
+                if s[d] != 0:
+                    m = hi_s[d] if s[d] > 0 else lo_s[d]
+                    mask = m if mask is None else (mask & m)
+            ids = sidx32[mask]
             ids_per_rank[self.dir_rank[k]].append(ids)
             codes_per_rank[self.dir_rank[k]].append(torch.full_like(ids, k))
         empty = torch.empty(0, dtype=torch.int32, device=dev)
