@@ -110,6 +110,8 @@ struct BrickArgs {
     Rec<real> *rec_next;       // position buffer of the next step
     real kick_c, dt, thr2;
     int *trigger;
+    // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
+    real uni_sigma2, uni_e4;
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
 }
 
 // ------------------------------------------------------------------------------------ force / stats
-template <typename real, class Shape, int THREADS, int G, int MODE, int BITMASK>
+template <typename real, class Shape, int THREADS, int G, int MODE, int BITMASK, bool UNI = false>
 __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
     constexpr int BLK = EPL * G;
@@ -574,7 +576,11 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
                         real E, W;
-                        lj_interaction(r2, inv_r2, mdl, hs_i, te_i, hs_j, te_j, E, W);
+                        if (UNI) {   // single species: no parameter gather, conversion or mixing per pair
+                            lj_interaction_pair(r2, inv_r2, mdl, a.uni_sigma2, a.uni_e4, E, W);
+                        } else {
+                            lj_interaction(r2, inv_r2, mdl, hs_i, te_i, hs_j, te_j, E, W);
+                        }
                         if (BITMASK & EMDEE_FORCES) {
                             const real wr2 = W * inv_r2;      // src/nonbonded.jl:139
                             fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;

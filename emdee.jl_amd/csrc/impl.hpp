@@ -93,7 +93,7 @@ struct NbrImpl : INbr {
         bool rebuild = !sys.has_list || sys.n_total != N;
         if (!rebuild) rebuild = sys.user_positions_moved(pos);
         if (rebuild) sys.load_user(N, 0, pos, nullptr, atoms, nullptr);
-        else sys.refresh_user(pos, atoms);
+        else { sys.detect_uniform_atoms(atoms); sys.refresh_user(pos, atoms); }   // the caller may have edited atoms
         sys.compute_forces(bitmask);
         sys.unsort(nullptr, nullptr, (bitmask & EMDEE_FORCES) ? (real *)forces : nullptr,
                    (bitmask & EMDEE_ENERGIES) ? (real *)energies : nullptr,

@@ -580,6 +580,16 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, 
     if (vir_out) vir_out[i] = vir[p];
 }
 
+// sets *flag if any LJAtom differs (bitwise) from the first one
+static __global__ void k_atoms_differ(int n, const emdee_lj_atom *__restrict__ atoms, int *__restrict__ flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const emdee_lj_atom a = atoms[i], b = atoms[0];
+    if (__float_as_int(a.half_sigma) != __float_as_int(b.half_sigma) ||
+        __float_as_int(a.twice_sqrt_eps) != __float_as_int(b.twice_sqrt_eps))
+        *flag = 1;
+}
+
 // fused decomposed step: ghost records (not owned, never integrated here) follow the buffer swap
 template <typename real>
 __global__ void k_copy_ghost_records(int n, int n_owned, const int *__restrict__ perm, const Rec<real> *__restrict__ src,

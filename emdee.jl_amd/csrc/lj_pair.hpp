@@ -51,15 +51,15 @@ __device__ __forceinline__ real switch_clamp(real x) {
     return x;
 }
 
-// Returns (E g, W g + E (-r g')) given r2 and inv_r2 = 1/r2.  CUTOFF semantics (r2 >= rc2
-// contributes nothing) are the CALLER's test; this is the literal function.
+// Returns (E g, W g + E (-r g')) given r2, inv_r2 = 1/r2 and the pair constants sigma2 = sigma_ij^2,
+// e4 = 4 eps_ij.  CUTOFF semantics (r2 >= rc2 contributes nothing) are the CALLER's test; this is the
+// literal function.
 template <typename real>
-__device__ __forceinline__ void lj_interaction(real r2, real inv_r2, const LJModel<real> &m, real hs_i, real te_i,
-                                               real hs_j, real te_j, real &E_out, real &W_out) {
-    const real sigma = hs_i + hs_j;                                    // :29
-    const real s2 = sigma * sigma * inv_r2;                            // :31
+__device__ __forceinline__ void lj_interaction_pair(real r2, real inv_r2, const LJModel<real> &m, real sigma2, real e4,
+                                                    real &E_out, real &W_out) {
+    const real s2 = sigma2 * inv_r2;                                   // :31
     const real s6 = s2 * s2 * s2;                                      // :32
-    const real e4s6 = te_i * te_j * s6;                                // :33  4 eps s^-6
+    const real e4s6 = e4 * s6;                                         // :33  4 eps s^-6
     const real t = e4s6 * s6;                                          //      4 eps s^-12
     const real E = t - e4s6;                                           // :34  4 eps (s^-12 - s^-6)
     const real W = (real)6 * (E + t);                                  // :35  24 eps (2 s^-12 - s^-6)
@@ -72,6 +72,15 @@ __device__ __forceinline__ void lj_interaction(real r2, real inv_r2, const LJMod
     const real mgr = m.c60 * (x2 * u2) * r2;                           // :40  -r g' = 60 x^2 (1-x)^2 idl2 r2
     E_out = E * g;                                                     // :41
     W_out = W * g + E * mgr;
+}
+
+// Lorentz-Berthelot through the LJAtom encoding: sigma_ij = half_sigma_i + half_sigma_j (:29),
+// 4 eps_ij = twice_sqrt_eps_i * twice_sqrt_eps_j (:30,33)
+template <typename real>
+__device__ __forceinline__ void lj_interaction(real r2, real inv_r2, const LJModel<real> &m, real hs_i, real te_i,
+                                               real hs_j, real te_j, real &E_out, real &W_out) {
+    const real sigma = hs_i + hs_j;
+    lj_interaction_pair(r2, inv_r2, m, sigma * sigma, te_i * te_j, E_out, W_out);
 }
 
 }  // namespace emdee

@@ -233,6 +233,7 @@ struct NbSystem {
         Timed t(this, T_REBUILD);
         n_owned = n_own;
         reserve(n_own + n_ghost, velocities != nullptr || with_vel, inv_mass != nullptr);
+        detect_uniform_atoms(atoms);
         configure_grid();
         const int n = n_total;
         bin(UserPos<real>{pos}, nullptr);
@@ -277,13 +278,26 @@ struct NbSystem {
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
         a.vel = vel.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
         a.kick_c = (real)step_c; a.dt = (real)step_dt;
+        a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.thr2 = (real)(0.25 * skin * skin); a.trigger = flags.ptr + 1;
         return a;
     }
 
     template <class V, int MODE, int BM>
     void launch_brick_kernel() {
-        auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM>;
+        // single-species fast path for the kernels of the MD loop (default variant only)
+        if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
+            if (uniform_atoms) {
+                launch_brick_kernel_impl<V, MODE, BM, true>();
+                return;
+            }
+        }
+        launch_brick_kernel_impl<V, MODE, BM, false>();
+    }
+
+    template <class V, int MODE, int BM, bool UNI>
+    void launch_brick_kernel_impl() {
+        auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM, UNI>;
         allow_big_lds(kernel, lds_bytes);
         const int phase = (MODE == BRICK_FORCE || MODE == BRICK_STEP) ? force_phase : 0;
         const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
@@ -430,6 +444,27 @@ struct NbSystem {
 
     int force_phase = 0;
     double step_c = 0.0, step_dt = 0.0;
+    bool uniform_atoms = false;            // every atom has the same LJAtom (checked when a state is loaded)
+    double uni_sigma2 = 0.0, uni_e4 = 0.0;
+
+    // Are all LJAtom records identical?  (One small kernel + an 8-byte read-back per load.)
+    void detect_uniform_atoms(const emdee_lj_atom *atoms) {
+        uniform_atoms = false;
+        if (n_total == 0 || std::getenv("EMDEE_NO_UNIFORM")) return;
+        EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));
+        hipLaunchKernelGGL(k_atoms_differ, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, atoms, flags.ptr + 5);
+        emdee_lj_atom first;
+        EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 5, flags.ptr + 5, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        if (ctx->host_flags[5] == 0) {
+            uniform_atoms = true;
+            // the same fp operations as the per-pair path: (hs + hs)^2 and te * te in the kernel's type
+            const real sg = (real)first.half_sigma + (real)first.half_sigma;
+            uni_sigma2 = (double)(sg * sg);
+            uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
+        }
+    }
 
     // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
     // the other position buffer.  False if the brick kernels are not in use (caller runs the split kernels).
