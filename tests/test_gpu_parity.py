@@ -384,3 +384,57 @@ def test_million_atoms_properties(emdee, oracle, dev):
     pairs = tiles.count_pairs()
     # n(rc)/2 = 26.18 pairs per atom in a uniform fluid; the jittered fcc shells give ~26.9
     assert abs(pairs / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 1.5
+
+
+# ------------------------------------------------------------------------- edge cases and the direct kernels
+def test_empty_and_tiny_md_states(emdee, oracle, dev):
+    E = emdee
+    model = E.LennardJonesModel(2.5, 2.0)
+    t64 = torch.float64
+    md = E.VelocityVerlet(torch.zeros((0, 3), dtype=t64, device=dev), torch.zeros((0, 3), dtype=t64, device=dev), 10.0, model,
+                          torch.zeros((0, 2), dtype=torch.float32, device=dev))
+    md.step_(3, 0.005)
+    assert md.totals() == (0.0, 0.0, 0.0) and md.state()["positions"].shape == (0, 3)
+    # two atoms, one pair, crossing the periodic boundary: analytic LJ at r = 1.1
+    x = np.array([[0.05, 5.0, 5.0], [9.95 - 1.0, 5.0, 5.0]])
+    x[1, 0] = 10.0 - 1.05                                           # minimum-image distance 1.1 through the wall
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 2)
+    md = E.VelocityVerlet(E.cu(x, dev), E.cu(np.zeros((2, 3)), dev), 10.0, model, E.cu(atoms, dev))
+    st = md.state(energies=True, virials=True)
+    r = 1.1
+    f_exact = 24.0 * (2.0 * r ** -12 - r ** -6) / r
+    assert st["forces"][0, 0].item() == pytest.approx(f_exact, rel=1e-12)      # pushed apart: +x for the atom at 0.05
+    assert st["forces"][1, 0].item() == pytest.approx(-f_exact, rel=1e-12)
+    assert st["energies"].sum().item() == pytest.approx(4.0 * (r ** -12 - r ** -6), rel=1e-12)
+    ref = oracle.verlet(x, np.zeros((2, 3)), 10.0, oracle.model(2.5, 2.0), atoms, 0.002, 50)
+    md.step_(50, 0.002)
+    dx = md.state()["positions"].cpu().numpy() - ref["x"]
+    assert np.abs(dx - 10.0 * np.rint(dx / 10.0)).max() < 1e-10
+
+
+def test_argument_errors_are_reported(emdee, dev):
+    E = emdee
+    x = torch.zeros((4, 3), dtype=torch.float64, device=dev)
+    a = E.cu(E.lennard_jones_atoms(1.0, 1.0, 4), dev)
+    f = torch.zeros((4, 3), dtype=torch.float64, device=dev)
+    with pytest.raises(E.EmDeeError, match="half the periodic box"):
+        E.compute_nonbonded_(f, None, None, x, 5.0, E.nonbonded_computation_tiles(4), E.LennardJonesModel(2.5, 2.0), a, E.FORCES)
+    with pytest.raises(ValueError):
+        E.compute_nonbonded_(f, None, None, x, 10.0, E.nonbonded_computation_tiles(5), E.LennardJonesModel(2.5, 2.0), a, E.FORCES)
+    with pytest.raises(TypeError):
+        E.compute_nonbonded_(f.float(), None, None, x, 10.0, E.nonbonded_computation_tiles(4), E.LennardJonesModel(2.5, 2.0), a, E.FORCES)
+    with pytest.raises(ValueError):
+        E.compute_nonbonded_(f, None, None, x, 10.0, E.nonbonded_computation_tiles(4), E.LennardJonesModel(2.5, 2.0), a, 9)
+
+
+def test_direct_kernels_and_general_species_path(oracle):
+    """The A/B baselines stay correct: the global-gather kernels (EMDEE_PATH=direct) and the per-pair
+    parameter path forced on a single-species box (EMDEE_NO_UNIFORM=1), each in a fresh process."""
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    sel = "neighbor_path_on_reference_fixture or verlet_100_steps_config0 or medium_box"
+    for env in ({"EMDEE_PATH": "direct"}, {"EMDEE_NO_UNIFORM": "1"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k", sel],
+                           cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
