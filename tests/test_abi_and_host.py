@@ -93,3 +93,24 @@ def test_synthetic_boxes(emdee_synthetic):
     # splitmix64 reference vector (first outputs of the generator seeded with 0)
     got = syn.splitmix64(np.array([0], dtype=np.uint64))[0]
     assert int(got) == 0xE220A8397B1DCDAF
+
+
+def test_ingest_xyz_forcefield_checkpoint(emdee, tmp_path):
+    """XYZ in/out, the NonbondedForce table of the reference's own force-field fixture
+    (test/data/dibenzo-p-dioxin-in-water.xml, parsed by the reference at src/modelling.jl:197-200), checkpoint."""
+    from .conftest import GOLDEN
+    ing = emdee.ingest
+    names, pos = ing.read_xyz(os.path.join(GOLDEN, "lj_sample.xyz"))
+    assert len(names) == 800 and pos.shape == (800, 3) and pos[0, 0] == pytest.approx(-1.126362593256e-01)
+    ing.write_xyz(tmp_path / "out.xyz", names, pos, "round trip")
+    names2, pos2 = ing.read_xyz(tmp_path / "out.xyz")
+    assert names2 == names and np.abs(pos2 - pos).max() < 1e-12
+    table = ing.NonbondedTable(os.path.join(GOLDEN, "dibenzo-p-dioxin-in-water.xml"))
+    assert table.lj14scale == 0.5 and table.coulomb14scale == pytest.approx(0.833333)
+    assert sorted(table.types) == ["HW", "OW", "ca", "ha", "os"]
+    atoms = table.lj_atoms(["OW", "HW", "HW", "ca"], length_unit=0.1)          # nm -> Angstrom
+    assert atoms["half_sigma"][0] == np.float32(0.5 * 3.16549212)
+    assert atoms["twice_sqrt_eps"][0] == np.float32(2.0 * np.sqrt(0.650299013)) and atoms["twice_sqrt_eps"][1] == 0.0
+    ing.save_checkpoint(tmp_path / "ck.npz", pos, 2.0 * pos, 17, 10.0)
+    x, v, step, L = ing.load_checkpoint(tmp_path / "ck.npz")
+    assert (x == pos).all() and (v == 2.0 * pos).all() and step == 17 and L == 10.0
