@@ -438,3 +438,50 @@ def test_direct_kernels_and_general_species_path(oracle):
         r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-k", sel],
                            cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", ["gas", "dense_solid", "slab", "elongated_cells"])
+def test_density_regimes(emdee, oracle, dev, case):
+    """Cell populations far from the benchmark's 17.6 atoms/cell: nearly empty tiles, packed tiles, a
+    half-empty box (empty bricks), and a box whose edge is not a multiple of the brick (partial bricks)."""
+    E = emdee
+    rng = np.random.default_rng(42)
+    rc, rs = 2.5, 2.0
+    if case == "gas":
+        L, N = 60.0, 10800                                            # rho* = 0.05
+        pos = rng.uniform(0, L, size=(N, 3))
+        # no overlapping pairs: push apart anything closer than 0.9 by re-drawing
+        for _ in range(20):
+            off, nb = oracle.neighbor_list(pos, L, 0.9)
+            bad = np.nonzero(np.diff(off) > 0)[0]
+            if bad.size == 0:
+                break
+            pos[bad] = rng.uniform(0, L, size=(bad.size, 3))
+    elif case == "dense_solid":
+        pos, L = E.synthetic.fcc_positions(16, rho=1.2, jitter=0.05)  # 16384 atoms
+    elif case == "slab":
+        p, L = E.synthetic.fcc_positions(18)                          # 23328 atoms, keep the lower half
+        pos = p[p[:, 2] < 0.5 * L]
+    else:
+        pos, L = E.synthetic.fcc_positions(19)                        # L = 32.49: 11 cells per dimension, bricks of 4/2/2
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(rc, rs), atoms)
+    tiles = E.nonbonded_computation_tiles(N)
+    f, e, w = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f, e, w, E.cu(pos, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), 7)
+    scale = max(np.abs(f0).max(), 1e-12)
+    assert np.abs(f.cpu().numpy() - f0).max() < REL64 * scale
+    assert np.abs(e.cpu().numpy() - e0).max() < REL64 * max(np.abs(e0).max(), 1e-12)
+    assert np.abs(w.cpu().numpy() - w0).max() < REL64 * max(np.abs(w0).max(), 1e-12)
+    off, _ = oracle.neighbor_list(pos, L, rc + 0.3)
+    st = tiles.stats()
+    assert st["listed"] == off[-1] and st["max_count"] == np.diff(off).max()
+    # a short trajectory through rebuilds
+    vel = 0.5 * rng.standard_normal(size=(N, 3))
+    vel -= vel.mean(axis=0)
+    ref = oracle.verlet(pos, vel, L, oracle.model(rc, rs), atoms, 0.004, 12)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(rc, rs), E.cu(atoms, dev))
+    md.step_(12, 0.004)
+    dx = md.state()["positions"].cpu().numpy() - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
