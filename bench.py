@@ -257,6 +257,20 @@ def main():
                     out["roofline"]["traffic_source"] = t.get("source")
             except Exception:
                 pass
+        # the same kernel against the limit that actually binds it in fp64 ("report VALU
+        # utilisation next to GB/s"): instruction counts from the committed SQ counter pass, live duration
+        valu = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(valu) and not args.mixture:
+            try:
+                with open(valu) as fh:
+                    t = json.load(fh)
+                if t.get("atoms") == N_rank and t.get("dtype") == out["dtype"] and force_avg_s > 0:
+                    out["valu_issue"] = {"kernel": "lj_force_nbr (fused)", "floor_ms": t["issue_floor_ms"],
+                                         "avg_launch_ms": force_avg_s * 1e3, "frac": t["issue_floor_ms"] / (force_avg_s * 1e3),
+                                         "valu_insts_per_launch": t["valu_insts_per_launch"], "fp64_share": t.get("fp64_share"),
+                                         "model": t.get("model"), "clock_ghz": t.get("clock_ghz"), "source": t.get("source")}
+            except Exception:
+                pass
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -629,10 +629,18 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         }
     }
     if (MODE == BRICK_STATS) {
-        // exact integer totals; one atomic per lane that has something to add
-        if (st_entries) atomicAdd(&a.stats[0], st_entries);
-        if (st_max) atomicMax(&a.stats[1], (unsigned long long)st_max);
-        if (st_inside) atomicAdd(&a.stats[2], st_inside);
+        // exact integer totals; reduced over the wavefront first (three hot addresses for the whole grid)
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            st_entries += __shfl_xor(st_entries, off);
+            st_inside += __shfl_xor(st_inside, off);
+            st_max = max(st_max, __shfl_xor(st_max, off));
+        }
+        if (lane == 0) {
+            if (st_entries) atomicAdd(&a.stats[0], st_entries);
+            if (st_max) atomicMax(&a.stats[1], (unsigned long long)st_max);
+            if (st_inside) atomicAdd(&a.stats[2], st_inside);
+        }
     }
 }
 

@@ -4,6 +4,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -44,7 +45,8 @@ def mean(d, pred):
     return sum(vals) / len(vals) if vals else None
 
 
-fused = lambda k: "k_brick<" in k and ", 3, 1>" in k
+# k_brick<real, Shape, THREADS, G, MODE = 3 (force + integrator), BITMASK = 1 [, single-species fast path]>
+fused = lambda k: re.search(r"k_brick<.*?, 3, 1[,>]", k) is not None
 kd = lambda k: "k_kick_drift" in k
 f_kb, w_kb = mean(fe, fused), mean(wr, fused)
 cal_f, cal_w = mean(fe, kd), mean(wr, kd)
@@ -58,4 +60,32 @@ if f_kb is not None and w_kb is not None:
         lj_force_nbr_bytes_per_launch=int((2 * f_kb + w_kb) * 1024), bytes_per_atom=(2 * f_kb + w_kb) * 1024 / N)
     json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
     print("traffic: %.1f B/atom per launch" % traffic["bytes_per_atom"])
+
+# ---- SQ instruction counters of the fused kernel: how close the kernel is to the VALU issue limit ----------
+sq = collections.defaultdict(list)
+for sub in ("pmc_sq1", "pmc_sq2"):
+    for f in glob.glob(os.path.join(out, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if fused(r["Kernel_Name"]):
+                sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq:
+    avg = {k: sum(v) / len(v) for k, v in sq.items()}
+    lines = ["rocprofv3 --kernel-trace --pmc <SQ counters, two passes of 8> -- python3 bench.py --steps 12 --warmup 3; N = %d" % N,
+             "fused lj_force_nbr kernel (k_brick MODE=3), mean per launch over %d launches" % len(next(iter(sq.values())))]
+    lines += ["%-28s %16.0f" % (k, v) for k, v in sorted(avg.items())]
+    # one wave64 VALU instruction holds its SIMD for 4 cycles (16 lanes/clk, fp64 FMA/MUL/ADD included);
+    # v_rcp_f64 and friends (TRANS) run at a quarter of that rate: 16 cycles
+    simds, clock_ghz = 256 * 4, 2.4
+    insts, trans = avg.get("SQ_INSTS_VALU", 0.0), avg.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    floor_ms = (insts * 4 + trans * 12) / simds / (clock_ghz * 1e6)
+    f64 = sum(avg.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("FMA", "MUL", "ADD", "TRANS"))
+    lines.append("VALU issue floor = (SQ_INSTS_VALU x 4 + TRANS_F64 x 12 cycles) / %d SIMDs / %.1f GHz = %.3f ms per launch" % (simds, clock_ghz, floor_ms))
+    lines.append("fp64 share of VALU instructions: %.2f" % (f64 / insts if insts else 0.0))
+    open(os.path.join(dst, "final_pmc_sq.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump(dict(source="profiles/%s/final_pmc_sq.txt (profiles/collect.sh)" % tag, atoms=N, dtype=bench["dtype"],
+                   valu_insts_per_launch=insts, valu_trans_f64_per_launch=trans, fp64_share=f64 / insts if insts else None,
+                   simds=simds, clock_ghz=clock_ghz, issue_floor_ms=floor_ms,
+                   model="wave64 VALU instruction = 4 SIMD cycles, TRANS_F64 = 16"),
+              open(os.path.join(root, "valu.json"), "w"), indent=1)
+    print("valu issue floor: %.3f ms per launch" % floor_ms)
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "step_roofline", "cpu_baseline") if k in bench})[:1500])
