@@ -324,7 +324,17 @@ __device__ __forceinline__ void brick_for_each_slot(const BrickTables<Shape, THR
 constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetched before the tile is staged
 
 // ------------------------------------------------------------------------------------ build
-template <typename real, class Shape, int THREADS, int G>
+// ALG 1: candidates are dealt round-robin to the lanes of a group and every pass of the test loop
+// compacts its hits with a ballot (count, prefix, scattered 2-byte LDS store: more VALU work than the
+// distance test itself).  ALG 2 (default when no 3-cell tile row holds more than BUILD2_MAX_SPAN atoms):
+// each lane tests a CONTIGUOUS chunk of every tile row and only records one bit per candidate; the hits
+// are compacted once per atom, from the bit fields, after a prefix sum over the lanes of the group.  Rows
+// come out ordered lane by lane, i.e. still along the tile rows, so neighbouring entries keep pointing at
+// neighbouring tile slots.
+constexpr int BUILD2_FIELD = 16;                      // bits per tile row in a lane's bit field
+template <int G> constexpr int build2_max_span() { return BUILD2_FIELD * G; }
+
+template <typename real, class Shape, int THREADS, int G, int ALG = 1>
 __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
@@ -396,6 +406,107 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     const unsigned ustride = (unsigned)a.stride;
     const unsigned fill2 = (unsigned)tile_n | ((unsigned)tile_n << 16);
     const uint4 fill = make_uint4(fill2, fill2, fill2, fill2);
+    // fp32 test of candidate slot c against atom (p, qi); pairs inside the rounding band are decided with
+    // the exact fp64 records (tcr = tile cell x-1 of the candidate's tile row)
+    auto in_range_q = [&](const float4 &qi, const float4 &qj, int p, int c, int tcr) -> bool {
+        const float dx = qi.x - qj.x, dy2 = qi.y - qj.y, dz2 = qi.z - qj.z;
+        const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+        bool pass = d2 < lo2;
+        if (sizeof(real) == 8 && __builtin_expect(!pass && d2 <= hi2, 0)) {
+            const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
+            const int sh = T.shift[tc];
+            const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(qj.w)];
+            const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
+            const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
+            const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
+            pass = ex * ex + ey * ey + ez * ez < a.rlist2;
+        }
+        return pass;
+    };
+    auto in_range = [&](const float4 &qi, int p, int c, int tcr) -> bool { return in_range_q(qi, tile[c], p, c, tcr); };
+    if constexpr (ALG == 2) {
+        static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
+        constexpr int NROWS = 9, NWORDS = (NROWS + 1) / 2;
+        for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
+            const int o = ob + gid;
+            const bool have = o < n_own;
+            int ti = 0, p = 0, oc = 0;
+            if (have) oc = brick_locate(T, o, ti, p);
+            const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+            const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
+            const float4 qi = tile[ti];
+            unsigned short *row = a.nbr + (size_t)p * a.stride;
+            for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
+            // ---- phase 1: one bit per candidate of my chunk of each of the 9 tile rows -------------
+            unsigned word[NWORDS];
+            int cbase[NROWS];
+#pragma unroll
+            for (int r = 0; r < NROWS; r++) {
+                const int dy = r % 3 - 1, dz = r / 3 - 1;
+                const int tcr = ox + TX * ((oy + 1 + dy) + TY * (oz + 1 + dz));   // cell x-1 of that tile row
+                const int c0 = T.off[tcr];
+                const int span = act ? T.off[tcr + 3] - c0 : 0;                    // cells x-1, x, x+1: contiguous
+                const int chunk = (span + G - 1) / G;                               // <= BUILD2_FIELD (host check)
+                const int first = gl * chunk;
+                const int lim = min(chunk, span - first);                           // my candidates; may be <= 0
+                const int cb = c0 + first;
+                cbase[r] = (r & 1) ? cb - BUILD2_FIELD : cb;
+                unsigned bits = 0;
+                float4 qc = tile[cb];                                               // one candidate ahead
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int k = 0; k < lim; k++) {                                     // divergent trip count
+                    const float4 qn = tile[cb + k + 1];                             // (past the chunk: harmless)
+                    bits |= (in_range_q(qi, qc, p, cb + k, tcr) ? 1u : 0u) << k;
+                    qc = qn;
+                }
+                if (r == 4) {                                                       // the atom itself
+                    const int ks = ti - cb;
+                    if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
+                }
+                if (r & 1) word[r / 2] |= bits << BUILD2_FIELD;
+                else word[r / 2] = bits;
+            }
+            // ---- phase 2: prefix over the lanes of the group, then every lane emits its hits --------
+            int mine = 0;
+#pragma unroll
+            for (int w = 0; w < NWORDS; w++) mine += __popc(word[w]);
+            int incl = mine;
+            {
+                int t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR1, 0xf, 0xf, true);
+                incl += gl >= 1 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR2, 0xf, 0xf, true);
+                incl += gl >= 2 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR4, 0xf, 0xf, true);
+                incl += gl >= 4 ? t : 0;
+                if (G == 16) {
+                    t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR8, 0xf, 0xf, true);
+                    incl += gl >= 8 ? t : 0;
+                }
+            }
+            unsigned e = (unsigned)(incl - mine);
+#pragma unroll
+            for (int w = 0; w < NWORDS; w++) {
+                unsigned W = word[w];
+                const int cA = cbase[2 * w], cB = (2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0;
+                while (W) {
+                    const int k = __ffs((int)W) - 1;
+                    W &= W - 1;
+                    const int c = k + (k >= BUILD2_FIELD ? cB : cA);
+                    if (e < ustride) rowbuf[row_position<G>(e)] = (unsigned short)c;
+                    e++;
+                }
+            }
+            if (have) {
+                for (int c = gl * EPL; c < a.stride; c += G * EPL)
+                    *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
+                if (gl == G - 1) {                            // the last lane's inclusive prefix is the row length
+                    a.cnt[p] = act ? (int)min((unsigned)incl, ustride) : 0;
+                    if ((unsigned)incl > ustride) atomicMax(&a.flags[0], incl);
+                }
+            }
+        }
+        return;
+    }
     for (int ob = 0; ob < n_own; ob += NGROUPS) {             // wave-uniform trip count
         const int o = ob + gid;
         const bool have = o < n_own;
@@ -418,22 +529,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                 for (int cb = 0; cb < wspan; cb += G) {
                     const int c = c0 + cb + gl;
                     bool pass = false;
-                    if (cb + gl < span && c != ti) {
-                        const float4 qj = tile[c];
-                        const float dx = qi.x - qj.x, dy2 = qi.y - qj.y, dz2 = qi.z - qj.z;
-                        const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
-                        pass = d2 < lo2;
-                        if (sizeof(real) == 8 && __builtin_expect(!pass && d2 <= hi2, 0)) {
-                            // inside the fp32 rounding band: decide with the exact fp64 records
-                            const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
-                            const int sh = T.shift[tc];
-                            const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(qj.w)];
-                            const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
-                            const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
-                            const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
-                            pass = ex * ex + ey * ey + ez * ez < a.rlist2;
-                        }
-                    }
+                    if (cb + gl < span && c != ti) pass = in_range(qi, p, c, tcr);
                     const unsigned long long mask = __ballot(pass);
                     const unsigned half = upper ? (unsigned)(mask >> 32) : (unsigned)mask;
                     const unsigned bits = (half >> gshift) & gmask;
@@ -645,12 +741,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 }
 
 // Largest tile (brick + halo population) and largest own population over all bricks -> sizes the
-// dynamic LDS of the brick kernels.  out[0] = max tile, out[1] = max own.
+// dynamic LDS of the brick kernels.  out[0] = max tile, out[1] = max own, out[2] = most atoms in three
+// consecutive cells of a tile row (what one group of the build kernel scans per row).
 template <class Shape>
 __global__ void k_brick_tile_max(BrickGrid bg, int Mx, int My, int Mz, int px, int py, int pz,
                                  const int *__restrict__ start, int *__restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    int total = 0, own = 0;
+    int total = 0, own = 0, span3 = 0;
     if (b < bg.nbricks) {
         const int bxi = b % bg.nb[0], byi = (b / bg.nb[0]) % bg.nb[1], bzi = b / (bg.nb[0] * bg.nb[1]);
         const int ox0 = bxi * Shape::BX, oy0 = byi * Shape::BY, oz0 = bzi * Shape::BZ;
@@ -662,15 +759,21 @@ __global__ void k_brick_tile_max(BrickGrid bg, int Mx, int My, int Mz, int px, i
                 if (gy > oy1 || gz > oz1) continue;
                 if (gy < 0) { if (!py) continue; gy += My; } else if (gy >= My) { if (!py) continue; gy -= My; }
                 if (gz < 0) { if (!pz) continue; gz += Mz; } else if (gz >= Mz) { if (!pz) continue; gz -= Mz; }
+                int p1 = 0, p2 = 0;   // the two previous cells of this tile row
                 for (int tx = 0; tx < Shape::TX; tx++) {
                     const int rx = ox0 - 1 + tx;
                     int gx = rx;
-                    if (gx > ox1) continue;
-                    if (gx < 0) { if (!px) continue; gx += Mx; } else if (gx >= Mx) { if (!px) continue; gx -= Mx; }
-                    const int c = gx + Mx * (gy + My * gz);
-                    const int pop = start[c + 1] - start[c];
-                    total += pop;
-                    if (rx >= ox0 && rx < ox1 && ry >= oy0 && ry < oy1 && rz >= oz0 && rz < oz1) own += pop;
+                    bool valid = gx <= ox1;
+                    if (gx < 0) { if (!px) valid = false; gx += Mx; } else if (gx >= Mx) { if (!px) valid = false; gx -= Mx; }
+                    int pop = 0;
+                    if (valid) {
+                        const int c = gx + Mx * (gy + My * gz);
+                        pop = start[c + 1] - start[c];
+                        total += pop;
+                        if (rx >= ox0 && rx < ox1 && ry >= oy0 && ry < oy1 && rz >= oz0 && rz < oz1) own += pop;
+                    }
+                    span3 = max(span3, pop + p1 + p2);
+                    p2 = p1; p1 = pop;
                 }
             }
     }
@@ -678,10 +781,12 @@ __global__ void k_brick_tile_max(BrickGrid bg, int Mx, int My, int Mz, int px, i
     for (int off = 1; off < WAVE; off <<= 1) {
         total = max(total, __shfl_xor(total, off));
         own = max(own, __shfl_xor(own, off));
+        span3 = max(span3, __shfl_xor(span3, off));
     }
     if ((threadIdx.x & (WAVE - 1)) == 0 && total > 0) {
         atomicMax(&out[0], total);
         atomicMax(&out[1], own);
+        atomicMax(&out[2], span3);
     }
 }
 

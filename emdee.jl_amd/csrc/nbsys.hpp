@@ -102,6 +102,8 @@ struct NbSystem {
     int variant = 0;
     BrickGrid bgrid{};
     int tile_cap = 0, own_cap = 0, row_block = 1;
+    int build_alg = 1;                    // k_brick_build ALG (2 = two-phase; 1 when a tile row is too crowded for it)
+    bool force_build1 = false;            // EMDEE_BUILD_ALG=1: A/B switch
     size_t lds_bytes = 0, lds_build_bytes = 0;
     int build_variant_threads = 0, build_variant_g = 0;
     float build_margin = 0.f;
@@ -118,6 +120,7 @@ struct NbSystem {
     NbSystem() {
         if (const char *e = std::getenv("EMDEE_PATH")) path = (std::string(e) == "direct") ? PATH_DIRECT : PATH_BRICK;
         if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
+        if (const char *e = std::getenv("EMDEE_BUILD_ALG")) force_build1 = std::atoi(e) == 1;
     }
 
     hipStream_t stream() const { return ctx->stream; }
@@ -355,14 +358,15 @@ struct NbSystem {
             bgrid.bb_y = bgrid.ib_n[2] * (bgrid.nb[1] - bgrid.ib_n[1]) * bgrid.nb[0];
             bgrid.bb_count = bgrid.nbricks - bgrid.ib_count;
             bgrid.bb_per_xcd = (bgrid.bb_count + NXCD - 1) / NXCD;
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 3, 0, 2 * sizeof(int), stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 6, 0, 3 * sizeof(int), stream()));
             hipLaunchKernelGGL((k_brick_tile_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
                                grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], start(),
-                               flags.ptr + 3);
-            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 3, flags.ptr + 3, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+                               flags.ptr + 6);
+            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 6, flags.ptr + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
-            tile_cap = std::max(64, (ctx->host_flags[3] + 1 + 15) / 16 * 16);   // + 1: the sentinel record
-            own_cap = std::max(64, (ctx->host_flags[4] + 15) / 16 * 16);
+            tile_cap = std::max(64, (ctx->host_flags[6] + 1 + 15) / 16 * 16);   // + 1: the sentinel record
+            own_cap = std::max(64, (ctx->host_flags[7] + 15) / 16 * 16);
+            build_alg = (!force_build1 && (V::G == 8 || V::G == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::G) ? 2 : 1;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
             build_variant_threads = V::THREADS; build_variant_g = V::G;
             row_block = EPL * V::G;
@@ -401,7 +405,10 @@ struct NbSystem {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
-                    auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G>;
+                    auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 1>;
+                    if constexpr (V::G == 8 || V::G == 16) {
+                        if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 2>;
+                    }
                     lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::G);
                     allow_big_lds(kernel, lds_build_bytes);
                     hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(),
