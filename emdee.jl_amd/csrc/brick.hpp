@@ -110,6 +110,7 @@ struct BrickArgs {
     Rec<real> *rec_next;       // position buffer of the next step
     real kick_c, dt, thr2;
     int *trigger;
+    const int *guard;          // run-ahead launches: do nothing if the previous step asked for a rebuild
     // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
     real uni_sigma2, uni_e4;
 };
@@ -567,6 +568,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
     BrickTables<Shape, THREADS> T;
     T.carve(s_dyn + tile_bytes + te_bytes);
+    if (MODE == BRICK_STEP && a.guard != nullptr && *a.guard != 0) {
+        // The host queued this step before it could know that the previous one moved an atom past skin/2:
+        // the list is stale, so this launch (and, through the propagated flag, every later one of the
+        // batch) leaves the state untouched.  The previous kernel has completed: the word is final.
+        if (threadIdx.x == 0) *a.trigger = 1;
+        return;
+    }
     int bxi, byi, bzi, tile_n, n_own;
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);

@@ -117,6 +117,7 @@ struct KernelTimer {
     size_t used = 0;
     double total_ms = 0.0;
     int64_t launches = 0;
+    int64_t dropped = 0;   // recorded launches that turned out to be no-ops (run-ahead steps past a rebuild request)
     ~KernelTimer() {
         for (auto &p : pairs) {
             (void)hipEventDestroy(p.first);
@@ -143,12 +144,15 @@ struct KernelTimer {
             total_ms += ms;
             launches++;
         }
+        launches -= dropped;
+        dropped = 0;
         used = 0;
     }
     void reset() {
         used = 0;
         total_ms = 0.0;
         launches = 0;
+        dropped = 0;
     }
 };
 

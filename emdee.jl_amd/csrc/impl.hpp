@@ -158,7 +158,25 @@ struct MdImpl : IMd {
         // the closing half kick of step s rides on the opening half kick of step s+1); the last step ends
         // with a plain force pass and the closing half kick.
         sys.kick_drift(0.5 * dt, dt);
-        for (int s = 1; s <= nsteps; s++) {
+        int s = 1;
+        if (rebuild_every == 0) {
+            // displacement-triggered rebuilds: the inner steps are queued a few at a time (one read-back per
+            // batch, NbSystem::fused_steps_run_ahead); same sequence of states as one step at a time
+            bool stale = sys.read_rebuild_flag();
+            while (s < nsteps) {
+                if (stale) { sys.resort(); since_build = 0; }
+                const int ran = sys.fused_steps_run_ahead(dt, dt, nsteps - s, &stale);
+                if (ran == 0) break;                          // direct kernels: one step at a time below
+                s += ran; since_build += ran;
+            }
+            if (s == nsteps) {
+                since_build++;
+                if (stale) { sys.resort(); since_build = 0; }
+                sys.compute_forces(EMDEE_FORCES);
+                s++;
+            }
+        }
+        for (; s <= nsteps; s++) {
             since_build++;
             bool rb = rebuild_every > 0 ? since_build >= rebuild_every : sys.read_rebuild_flag();
             if (rb) { sys.resort(); since_build = 0; }

@@ -282,7 +282,9 @@ struct NbSystem {
         a.vel = vel.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
         a.kick_c = (real)step_c; a.dt = (real)step_dt;
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
-        a.thr2 = (real)(0.25 * skin * skin); a.trigger = flags.ptr + 1;
+        a.thr2 = (real)(0.25 * skin * skin);
+        a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
+        a.guard = step_guard;
         return a;
     }
 
@@ -491,6 +493,39 @@ struct NbSystem {
             rec.swap(rec2);
         }
         return true;
+    }
+
+    // Up to RUN_AHEAD fused steps queued back to back, with ONE read-back for the whole batch instead of a
+    // host round trip per step: launch i raises word i when an atom has moved skin/2, launch i + 1 looks at
+    // word i first and turns itself into a no-op (passing the word on).  Returns how many steps really ran
+    // (>= 1; 0 if the brick kernels are not in use); *stale says whether the last of them asked for a rebuild.
+    static constexpr int RUN_AHEAD = 4;
+    int *step_trigger = nullptr;
+    const int *step_guard = nullptr;
+    int fused_steps_run_ahead(double c, double dt, int want, bool *stale) {
+        EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
+        *stale = false;
+        if (!brick_active || n_total == 0 || n_total > n_owned) return 0;
+        const int B = std::max(1, std::min(want, RUN_AHEAD));
+        int *words = flags.ptr + 9;                          // flags[9 .. 9 + RUN_AHEAD)
+        EMDEE_HIP_CHECK(hipMemsetAsync(words, 0, B * sizeof(int), stream()));
+        step_c = c; step_dt = dt; force_phase = 0;
+        for (int i = 0; i < B; i++) {
+            Timed t(this, T_STEP);
+            step_trigger = words + i;
+            step_guard = i ? words + i - 1 : nullptr;
+            with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
+            rec.swap(rec2);
+        }
+        step_trigger = nullptr; step_guard = nullptr;
+        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 9, words, B * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        int ran = B;
+        for (int i = 0; i < B; i++)
+            if (ctx->host_flags[9 + i]) { ran = i + 1; *stale = true; break; }
+        if ((B - ran) & 1) rec.swap(rec2);                   // the skipped launches did not advance the ping-pong
+        if (profiling) timers[T_STEP].dropped += B - ran;
+        return ran;
     }
 
     void compute_forces(int bitmask, int phase = 0) {
