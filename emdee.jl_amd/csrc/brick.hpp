@@ -653,6 +653,10 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
         const int p = info.x, ti = info.y & 0xffff, m = (int)((unsigned)info.y >> 16);
         const IdxBuf cur = nxt;
+        // rows longer than the prefetched blocks (rc = 3.5 sigma: 184 entries): the next block is requested
+        // now and arrives while the first NPF blocks are being worked on
+        uint4 more = make_uint4(0, 0, 0, 0);
+        if (NPF * BLK < m) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + NPF * BLK + gl * EPL);
         nxt = fetch(o + NGROUPS);
         const int wm = wave_group_max<G>(m);
         real xi, yi, zi, hs_i, te_i;
@@ -698,9 +702,10 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 #pragma unroll
         for (int k = 0; k < NPF; k++)
             if (k * BLK < wm) block(cur.q[k], k * BLK);
-        for (int b0 = NPF * BLK; b0 < wm; b0 += BLK) {        // longer rows (rare): synchronous load
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (b0 < m) q = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + gl * EPL);
+        for (int b0 = NPF * BLK; b0 < wm; b0 += BLK) {        // longer rows: one block ahead
+            const uint4 q = more;
+            more = make_uint4(0, 0, 0, 0);
+            if (b0 + BLK < m) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + BLK + gl * EPL);
             block(q, b0);
         }
         if (MODE == BRICK_STATS) {
