@@ -121,6 +121,7 @@ struct NbSystem {
         if (const char *e = std::getenv("EMDEE_PATH")) path = (std::string(e) == "direct") ? PATH_DIRECT : PATH_BRICK;
         if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
         if (const char *e = std::getenv("EMDEE_BUILD_ALG")) force_build1 = std::atoi(e) == 1;
+        if (const char *e = std::getenv("EMDEE_RUN_AHEAD")) run_ahead = std::max(1, std::min(RUN_AHEAD, std::atoi(e)));
     }
 
     hipStream_t stream() const { return ctx->stream; }
@@ -500,13 +501,14 @@ struct NbSystem {
     // word i first and turns itself into a no-op (passing the word on).  Returns how many steps really ran
     // (>= 1; 0 if the brick kernels are not in use); *stale says whether the last of them asked for a rebuild.
     static constexpr int RUN_AHEAD = 4;
+    int run_ahead = RUN_AHEAD;            // EMDEE_RUN_AHEAD=1: one step per round trip (profiling: no no-op launches)
     int *step_trigger = nullptr;
     const int *step_guard = nullptr;
     int fused_steps_run_ahead(double c, double dt, int want, bool *stale) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         *stale = false;
         if (!brick_active || n_total == 0 || n_total > n_owned) return 0;
-        const int B = std::max(1, std::min(want, RUN_AHEAD));
+        const int B = std::max(1, std::min(want, run_ahead));
         int *words = flags.ptr + 9;                          // flags[9 .. 9 + RUN_AHEAD)
         EMDEE_HIP_CHECK(hipMemsetAsync(words, 0, B * sizeof(int), stream()));
         step_c = c; step_dt = dt; force_phase = 0;

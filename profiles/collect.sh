@@ -6,6 +6,9 @@
 TAG=${1:-r01}; R=$PWD; OUT=$R/gpurun_out/collect_$TAG; mkdir -p $OUT
 timeout -k 10 500 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "bench failed"
 cd /tmp && export TMPDIR=/tmp
+# profiled runs queue one step per host round trip: with run-ahead batches some launches of the step kernel are
+# no-ops (a rebuild was requested by the previous step) and would dilute the per-launch averages
+export EMDEE_RUN_AHEAD=1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1 || echo "stats failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || echo "fetch failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || echo "write failed"
