@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--mixture", action="store_true", help="binary LJ mixture (config 5)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="0 = displacement trigger; k = fixed cadence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--langevin", type=float, default=0.0,
+                    help="friction of the Langevin thermostat (T* = 1); 0 = NVE, the BASELINE workload")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged halo, for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU rehearsal, with --backend gloo)")
@@ -158,6 +160,8 @@ def main():
         run = lambda k: domain.step_(k, args.dt, args.rebuild_every)
         engine = domain.md
         parallelism = "dd%s" % "x".join(str(g) for g in domain.grid)
+    if args.langevin > 0.0:                # not the BASELINE workload: prices the thermostat (config.thermostat says so)
+        (md if world == 1 else domain).set_langevin_(args.langevin, 1.0, 0x5EED)
 
     def fence():
         if dist is not None:
@@ -226,7 +230,8 @@ def main():
                                % (rc, rs, " binary mixture" if args.mixture else "", N_total, args.cells, args.dt, args.skin),
                    "atoms": N_total, "atoms_per_gpu": N_rank, "parallelism": parallelism,
                    "aggregate": "value = n_gpus x steps/s of the decomposed box (one brick of %d^3x4 atoms per GPU)" % args.cells,
-                   "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2"},
+                   "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
+                   "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
         "pair_interactions_per_sec": pairs * steps_per_sec,
         "pairs_in_cutoff": pairs,
         "atom_steps_per_sec": N_total * steps_per_sec,

@@ -79,6 +79,9 @@ SIGNATURES = {
     "emdee_md_count_pairs": [_p, C.POINTER(_i64)],
     "emdee_md_profile": [_p, _i32],
     "emdee_md_kernel_time": [_p, _i32, C.POINTER(_dbl), C.POINTER(_i64)],
+    "emdee_md_set_langevin": [_p, _dbl, _dbl, C.c_uint64, C.c_uint64],
+    "emdee_md_set_langevin_ids": [_p, _p],
+    "emdee_md_langevin_normals": [_p, C.c_uint64, C.c_uint64, _p, _i32, _p],
     "emdee_last_error": [],
 }
 _RESTYPES = {"emdee_last_error": C.c_char_p}

@@ -111,6 +111,8 @@ struct BrickArgs {
     real kick_c, dt, thr2;
     int *trigger;
     const int *guard;          // run-ahead launches: do nothing if the previous step asked for a rebuild
+    const real *noise;         // Langevin O step between kick and drift: v = lgv_c1 v + noise[p]; NULL = NVE
+    real lgv_c1;
     // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
     real uni_sigma2, uni_e4;
 };
@@ -662,11 +664,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         real xi, yi, zi, hs_i, te_i;
         tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
-        real vx = 0, vy = 0, vz = 0, bx = 0, by = 0, bz = 0, imv = 1;
+        real vx = 0, vy = 0, vz = 0, bx = 0, by = 0, bz = 0, imv = 1, nx = 0, ny = 0, nz = 0;
         if (MODE == BRICK_STEP && have && gl == G - 1) {      // owner lane: its loads fly during the pair loop
             vx = a.vel[p]; vy = a.vel[a.pitch + p]; vz = a.vel[2 * a.pitch + p];
             bx = a.xb[p]; by = a.xb[a.pitch + p]; bz = a.xb[2 * a.pitch + p];
             if (a.inv_mass) imv = a.inv_mass[p];
+            if (a.noise) { nx = a.noise[p]; ny = a.noise[a.pitch + p]; nz = a.noise[2 * a.pitch + p]; }
         }
         // one block of 8 G neighbours: lane gl holds entries b0 + gl + t G, t = 0..7, in q
         auto block = [&](const uint4 &q, int b0) {
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                 if (have && gl == G - 1) {
                     const real cm = a.kick_c * imv;
                     vx += cm * fx; vy += cm * fy; vz += cm * fz;
+                    if (a.noise) { vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz; }
                     a.vel[p] = vx; a.vel[a.pitch + p] = vy; a.vel[2 * a.pitch + p] = vz;
                     Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
                     r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz;

@@ -377,5 +377,19 @@ int32_t emdee_md_profile(emdee_md *md, int32_t enable) {
 int32_t emdee_md_kernel_time(emdee_md *md, int32_t kernel, double *total_ms, int64_t *launches) {
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->kernel_time(kernel, total_ms, launches); });
 }
+int32_t emdee_md_set_langevin(emdee_md *md, double gamma, double temperature, uint64_t seed, uint64_t first_step) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->set_langevin(gamma, temperature, seed, first_step); });
+}
+int32_t emdee_md_set_langevin_ids(emdee_md *md, const int64_t *ids_dev) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->set_langevin_ids(ids_dev); });
+}
+int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, const int64_t *ids_dev, int32_t n,
+                                  double *out_dev) {
+    return guarded([&] {
+        REQUIRE_PTR(md, "md");
+        EMDEE_REQUIRE(n >= 0 && (n == 0 || (ids_dev && out_dev)), EMDEE_ERR_INVALID, "langevin_normals: bad arguments");
+        md->impl->langevin_normals(seed, step, ids_dev, n, out_dev);
+    });
+}
 
 }  // extern "C"

@@ -42,6 +42,9 @@ struct IMd {
     virtual void count_pairs(int64_t *pairs) = 0;
     virtual void profile(bool enable) = 0;
     virtual void kernel_time(int kernel, double *total_ms, int64_t *launches) = 0;
+    virtual void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) = 0;
+    virtual void set_langevin_ids(const int64_t *ids) = 0;
+    virtual void langevin_normals(uint64_t seed, uint64_t step, const int64_t *ids, int n, double *out) = 0;
 };
 
 template <typename real>

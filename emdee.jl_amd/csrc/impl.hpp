@@ -272,6 +272,17 @@ struct MdImpl : IMd {
         if (total_ms) *total_ms = sys.timers[kernel].total_ms;
         if (launches) *launches = sys.timers[kernel].launches;
     }
+    void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) override {
+        sys.set_langevin(gamma, temperature, seed, first_step, sys.lgv_ids);
+    }
+    void set_langevin_ids(const int64_t *ids) override { sys.lgv_ids = reinterpret_cast<const long long *>(ids); }
+    void langevin_normals(uint64_t seed, uint64_t step, const int64_t *ids, int n, double *out) override {
+        use_device(sys.ctx);
+        if (n <= 0) return;
+        hipLaunchKernelGGL((k_langevin_normals_test<real>), dim3(blocks_for(n, 256)), dim3(256), 0, sys.stream(), n,
+                           (unsigned long long)seed, (unsigned long long)step, reinterpret_cast<const long long *>(ids), out);
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
 };
 
 // ------------------------------------------------------------------------------------ factories

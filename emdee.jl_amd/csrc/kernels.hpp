@@ -522,10 +522,12 @@ __global__ __launch_bounds__(FORCE_BLOCK) void k_lj_force_nbr(int n, int n_owned
 // verlet_kick_drift: v += c f / m ; x += dt v, one pass (c = dt/2 for a lone half kick, dt when
 // the closing half kick of the previous step is fused in), plus the rebuild trigger:
 // |x - x_build|^2 > (skin/2)^2 raises *flag.
+// noise != NULL: Langevin O step between the kick and the drift, v = c1 v + noise (k_langevin_noise).
 template <typename real>
 __global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__restrict__ perm, Rec<real> *__restrict__ rec,
                              real *__restrict__ vel, const real *__restrict__ frc, const real *__restrict__ inv_mass,
-                             real c, real dt, const real *__restrict__ xb, real thr2, int *__restrict__ flag) {
+                             real c, real dt, const real *__restrict__ xb, real thr2, int *__restrict__ flag,
+                             const real *__restrict__ noise, real c1) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     if (perm[p] >= n_owned) return;
@@ -534,11 +536,67 @@ __global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__rest
     real vx = vel[p] + cm * frc[p];
     real vy = vel[pitch + p] + cm * frc[pitch + p];
     real vz = vel[2 * pitch + p] + cm * frc[2 * pitch + p];
+    if (noise) {
+        vx = c1 * vx + noise[p]; vy = c1 * vy + noise[pitch + p]; vz = c1 * vz + noise[2 * pitch + p];
+    }
     vel[p] = vx; vel[pitch + p] = vy; vel[2 * pitch + p] = vz;
     r.x += dt * vx; r.y += dt * vy; r.z += dt * vz;
     rec[p] = r;
     const real dx = r.x - xb[p], dy = r.y - xb[pitch + p], dz = r.z - xb[2 * pitch + p];
     if (dx * dx + dy * dy + dz * dz > thr2) *flag = 1;
+}
+
+// ---- Langevin thermostat (build-defined; the reference has neither integrator nor thermostat) ----------
+// Three N(0,1) numbers per (seed, step, atom id): splitmix64-finalised counters + Box-Muller, so the noise of
+// an atom does not depend on where the sort put it or on which rank owns it.  Same integer arithmetic as
+// oracle/emdee_oracle.c orc_langevin_normals.
+__device__ __forceinline__ unsigned long long lgv_mix(unsigned long long z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ void lgv_normals(unsigned long long seed, unsigned long long step, unsigned long long id,
+                                            double out[3]) {
+    const unsigned long long base = lgv_mix(seed + 0x9E3779B97F4A7C15ull * id);
+    const unsigned long long s2 = lgv_mix(base ^ (0xD1B54A32D192ED03ull * (step + 1)));
+    unsigned long long r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = lgv_mix(s2 + 0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1));
+    const double two53 = 1.0 / 9007199254740992.0, twopi = 6.283185307179586476925286766559;
+    const double u1 = (double)((r[0] >> 11) + 1) * two53, v2 = (double)(r[1] >> 11) * two53;
+    const double u3 = (double)((r[2] >> 11) + 1) * two53, v4 = (double)(r[3] >> 11) * two53;
+    const double a = sqrt(-2.0 * log(u1)), b = sqrt(-2.0 * log(u3));
+    double sn, cs;
+    sincos(twopi * v2, &sn, &cs);
+    out[0] = a * cs;
+    out[1] = a * sn;
+    out[2] = b * cos(twopi * v4);
+}
+// noise[p] = c2 sqrt(T / m_p) xi(seed, step, id_p) in cell order, one thread per atom (the fused step kernel's
+// owner lanes only pick the three numbers up: the transcendental work stays out of the pair kernel)
+template <typename real>
+__global__ void k_langevin_noise(int n, int n_owned, size_t pitch, const int *__restrict__ perm,
+                                 const long long *__restrict__ ids, const real *__restrict__ inv_mass,
+                                 unsigned long long seed, unsigned long long step, double c2, double temperature,
+                                 real *__restrict__ noise) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = perm[p];
+    if (i >= n_owned) return;
+    double xi[3];
+    lgv_normals(seed, step, (unsigned long long)(ids ? ids[i] : (long long)i), xi);
+    const double amp = c2 * sqrt(temperature * (inv_mass ? (double)inv_mass[p] : 1.0));
+    noise[p] = (real)(amp * xi[0]); noise[pitch + p] = (real)(amp * xi[1]); noise[2 * pitch + p] = (real)(amp * xi[2]);
+}
+template <typename real>
+__global__ void k_langevin_normals_test(int n, unsigned long long seed, unsigned long long step, const long long *ids,
+                                        double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xi[3];
+    lgv_normals(seed, step, (unsigned long long)ids[i], xi);
+    out[3 * i] = xi[0]; out[3 * i + 1] = xi[1]; out[3 * i + 2] = xi[2];
 }
 
 // verlet_kick: v += c f / m

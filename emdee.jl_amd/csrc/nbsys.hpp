@@ -110,7 +110,7 @@ struct NbSystem {
 
     DevBuf<Rec<real>> rec, rec2;
     DevBuf<float> te, te2;
-    DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb;
+    DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
     DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags, img, img2;
     DevBuf<unsigned short> nbr16;
     DevBuf<double> partial, sums;
@@ -236,6 +236,7 @@ struct NbSystem {
         EMDEE_REQUIRE(n_own + n_ghost == 0 || (pos && atoms), EMDEE_ERR_INVALID, "positions/atoms are NULL");
         Timed t(this, T_REBUILD);
         n_owned = n_own;
+        lgv_ids = nullptr;                                   // caller-order array of the previous state
         reserve(n_own + n_ghost, velocities != nullptr || with_vel, inv_mass != nullptr);
         detect_uniform_atoms(atoms);
         configure_grid();
@@ -286,6 +287,7 @@ struct NbSystem {
         a.thr2 = (real)(0.25 * skin * skin);
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
+        a.noise = lgv_on ? noise.ptr : nullptr; a.lgv_c1 = (real)lgv_c1;
         return a;
     }
 
@@ -476,15 +478,41 @@ struct NbSystem {
         }
     }
 
+    // ---------------------------------------------------------------- Langevin thermostat (optional)
+    // O step between the kick and the drift of every step: v = c1 v + c2 sqrt(T/m) xi(seed, step, id).
+    bool lgv_on = false;
+    double lgv_gamma = 0.0, lgv_T = 0.0, lgv_c1 = 1.0;
+    unsigned long long lgv_seed = 0, lgv_step = 0;
+    const long long *lgv_ids = nullptr;    // caller-order ids for the noise counters (NULL: the caller index)
+    void set_langevin(double gamma, double temperature, unsigned long long seed, unsigned long long first_step,
+                      const long long *ids) {
+        EMDEE_REQUIRE(std::isfinite(gamma) && std::isfinite(temperature) && temperature >= 0.0, EMDEE_ERR_INVALID,
+                      "langevin: gamma and temperature must be finite, temperature >= 0");
+        lgv_on = gamma > 0.0;
+        lgv_gamma = gamma; lgv_T = temperature; lgv_seed = seed; lgv_step = first_step; lgv_ids = ids;
+    }
+    // noise of the step about to be integrated (cell order); the caller advances lgv_step once per step
+    void prepare_noise(double dt) {
+        if (!lgv_on || n_total == 0) return;
+        noise.ensure(3 * pitch);
+        lgv_c1 = std::exp(-lgv_gamma * dt);
+        const double c2 = std::sqrt(1.0 - lgv_c1 * lgv_c1);
+        hipLaunchKernelGGL((k_langevin_noise<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
+                           n_owned, pitch, perm.ptr, lgv_ids, with_mass ? im.ptr : nullptr, lgv_seed, lgv_step, c2, lgv_T,
+                           noise.ptr);
+    }
+
     // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
     // the other position buffer.  False if the brick kernels are not in use (caller runs the split kernels).
     bool fused_step(double c, double dt, int phase = 0) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         if (!brick_active || n_total == 0) return false;
+        if (phase != 2) prepare_noise(dt);                   // phases 1 and 2 are the two halves of one step
         Timed t(this, T_STEP);
         step_c = c; step_dt = dt;
         force_phase = phase;
         with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
+        if (phase != 1 && lgv_on) lgv_step++;
         // Ghost records are never written by the step kernel: carry their current image over so that the
         // buffer that becomes current next is complete even before the next halo unpack.
         if (phase != 1) {
@@ -513,6 +541,8 @@ struct NbSystem {
         EMDEE_HIP_CHECK(hipMemsetAsync(words, 0, B * sizeof(int), stream()));
         step_c = c; step_dt = dt; force_phase = 0;
         for (int i = 0; i < B; i++) {
+            prepare_noise(dt);
+            if (lgv_on) lgv_step++;
             Timed t(this, T_STEP);
             step_trigger = words + i;
             step_guard = i ? words + i - 1 : nullptr;
@@ -526,6 +556,7 @@ struct NbSystem {
         for (int i = 0; i < B; i++)
             if (ctx->host_flags[9 + i]) { ran = i + 1; *stale = true; break; }
         if ((B - ran) & 1) rec.swap(rec2);                   // the skipped launches did not advance the ping-pong
+        if (lgv_on) lgv_step -= (unsigned long long)(B - ran);
         if (profiling) timers[T_STEP].dropped += B - ran;
         return ran;
     }
@@ -556,11 +587,13 @@ struct NbSystem {
     void kick_drift(double c, double dt) {
         EMDEE_REQUIRE(sorted && with_vel, EMDEE_ERR_STATE, "no velocities loaded");
         if (n_total == 0) return;
+        prepare_noise(dt);
         Timed t(this, T_KICK_DRIFT);
         real thr = (real)(0.5 * skin);
         hipLaunchKernelGGL((k_kick_drift<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
                            pitch, perm.ptr, rec.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c, (real)dt,
-                           xb.ptr, thr * thr, flags.ptr + 1);
+                           xb.ptr, thr * thr, flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1);
+        if (lgv_on) lgv_step++;
     }
 
     void kick(double c) {

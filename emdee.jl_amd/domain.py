@@ -241,6 +241,7 @@ class DecomposedVerlet:
         self.overlap = plan.transport == "device" and os.environ.get("EMDEE_DD_OVERLAP", "1") != "0"
         self.fused = os.environ.get("EMDEE_DD_FUSED", "1") != "0"
         self.since_build = 0
+        self._langevin = None
         self._load(x, v, atoms, gid)
 
     @property
@@ -267,6 +268,15 @@ class DecomposedVerlet:
         self.atoms = atoms
         self.since_build = 0
         self._shifts = [c for row in plan.shift_table.tolist() for c in row]
+        if self._langevin is not None:                 # the engine forgets the id array with the old state
+            self.md.set_langevin_ids_(self.gid)
+
+    def set_langevin_(self, gamma, temperature, seed=0, first_step=0):
+        """Langevin thermostat on every rank; the noise is keyed by GLOBAL atom ids, so the decomposed run
+        draws the numbers the undivided run would."""
+        self._langevin = (gamma, temperature, seed) if gamma > 0 else None
+        self.md.set_langevin_(gamma, temperature, seed, first_step)
+        self.md.set_langevin_ids_(self.gid if self._langevin is not None else None)
 
     def _with_halo(self, compute):
         """The per-step pattern: pack -> exchange (in flight on the collective's stream) || compute(phase 1:

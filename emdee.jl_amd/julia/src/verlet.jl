@@ -1,6 +1,6 @@
 # verlet.jl -- velocity-Verlet on the device.  Build-defined: the reference has no integrator
 # (SURVEY.md 8a row a16).  API in EmDee's style: a constructor and `!` mutators.
-export VelocityVerlet, step!, energies
+export VelocityVerlet, step!, energies, set_langevin!
 
 mutable struct VelocityVerlet{T}
     handle::Ptr{Cvoid}
@@ -30,6 +30,12 @@ end
 # int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every);
 step!(md::VelocityVerlet, nsteps, dt; rebuild_every=0) =
     check(ccall((:emdee_md_step, libemdee_hip), Int32, (Ptr{Cvoid}, Int32, Float64, Int32), md.handle, nsteps, dt, rebuild_every))
+
+# int32_t emdee_md_set_langevin(emdee_md *md, double gamma, double temperature, uint64_t seed, uint64_t first_step);
+# gamma > 0: every later step does v = c1 v + c2 sqrt(T/m) xi(seed, step, atom) between its kick and its drift.
+set_langevin!(md::VelocityVerlet, gamma, temperature; seed=0, first_step=0) =
+    check(ccall((:emdee_md_set_langevin, libemdee_hip), Int32, (Ptr{Cvoid}, Float64, Float64, UInt64, UInt64),
+                md.handle, gamma, temperature, seed, first_step))
 
 # int32_t emdee_md_energies(emdee_md *md, double out[3]);   -> (potential, kinetic, virial sum)
 function energies(md::VelocityVerlet)

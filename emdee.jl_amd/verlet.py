@@ -46,6 +46,7 @@ class VelocityVerlet:
         if inv_mass is not None:
             check_array(inv_mass, "inv_mass", n_owned, None, self.dtype, self.device)
         self.n_owned, self.n_ghost = n_owned, int(n_ghost)
+        self._langevin_ids = None                      # the library forgets the id array with the old state
         _lib.call("emdee_md_set_state", self._handle, n_owned, int(n_ghost), C.c_void_p(positions.data_ptr()),
                   C.c_void_p(velocities.data_ptr()), C.c_void_p(atoms.data_ptr()),
                   C.c_void_p(inv_mass.data_ptr()) if inv_mass is not None else None)
@@ -133,6 +134,29 @@ class VelocityVerlet:
         _lib.call("emdee_md_kernel_time", self._handle, KERNELS[kernel] if isinstance(kernel, str) else int(kernel),
                   C.byref(ms), C.byref(k))
         return ms.value, k.value
+
+    # -- Langevin thermostat
+    def set_langevin_(self, gamma, temperature, seed=0, first_step=0):
+        """gamma > 0: every later step does v = c1 v + c2 sqrt(T/m) xi between its kick and its drift
+        (include/emdee_hip.h: emdee_md_set_langevin); gamma <= 0 switches the thermostat off."""
+        _lib.call("emdee_md_set_langevin", self._handle, float(gamma), float(temperature), int(seed) & (2 ** 64 - 1),
+                  int(first_step))
+
+    def set_langevin_ids_(self, ids):
+        """int64 ids (device, caller order, owned atoms) keying the noise; None = the caller index.  Must be set
+        again after every set_state_."""
+        if ids is not None:
+            check_array(ids, "ids", self.n_owned, None, torch.int64, self.device)
+        self._langevin_ids = ids
+        _lib.call("emdee_md_set_langevin_ids", self._handle, C.c_void_p(ids.data_ptr()) if ids is not None else None)
+
+    def langevin_normals(self, seed, step, ids):
+        """The thermostat's generator on its own: (len(ids), 3) float64 tensor of N(0,1) numbers."""
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty((ids.shape[0], 3), dtype=torch.float64, device=self.device)
+        _lib.call("emdee_md_langevin_normals", self._handle, int(seed) & (2 ** 64 - 1), int(step),
+                  C.c_void_p(ids.data_ptr()), int(ids.shape[0]), C.c_void_p(out.data_ptr()))
+        return out
 
     def close(self):
         if self._handle is not None:

@@ -223,6 +223,22 @@ int32_t emdee_md_count_pairs(emdee_md *md, int64_t *pairs_in_cutoff);
 int32_t emdee_md_profile(emdee_md *md, int32_t enable);
 int32_t emdee_md_kernel_time(emdee_md *md, int32_t kernel, double *total_ms, int64_t *launches);
 
+/* Langevin thermostat (build-defined like the integrator: the reference has neither).
+ * gamma > 0 switches it on for every later step of this integrator, gamma <= 0 off.  Each step becomes
+ *   v += (dt/2) f/m ;  v = c1 v + c2 sqrt(T/m) xi ;  x += dt v ;  f = F(x) ;  v += (dt/2) f/m
+ * with c1 = exp(-gamma dt), c2 = sqrt(1 - c1^2) and xi three N(0,1) numbers that are a pure function of
+ * (seed, step number, atom id): splitmix64-finalised counters + Box-Muller, so a run is reproducible whatever
+ * the sort order or the decomposition.  Steps are numbered from first_step (pass the number of steps already
+ * done when resuming).  The O step rides in the kick/drift pass (the fused step kernel or verlet_kick_drift);
+ * the noise itself comes from one extra streaming kernel per step. */
+int32_t emdee_md_set_langevin(emdee_md *md, double gamma, double temperature, uint64_t seed, uint64_t first_step);
+/* Atom ids for the noise counters: device array in caller order, one int64 per owned atom (decomposed runs pass
+ * global ids); NULL = the caller index.  Not copied: must stay valid, and is forgotten by emdee_md_set_state. */
+int32_t emdee_md_set_langevin_ids(emdee_md *md, const int64_t *ids_dev);
+/* The generator on its own, for tests: out_dev[3 i .. 3 i + 2] = xi(seed, step, ids_dev[i]). */
+int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, const int64_t *ids_dev, int32_t n,
+                                  double *out_dev);
+
 #ifdef __cplusplus
 }
 #endif

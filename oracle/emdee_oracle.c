@@ -192,4 +192,69 @@ void orc_verlet_f64(int32_t N, double *x, double *v, double L, const orc_model64
     free(f); free(e); free(w);
 }
 
+/* ---- Langevin thermostat (build-defined, like the integrator itself: SURVEY 8f item 4) -----------------
+ * Counter-based normals: every (seed, step, atom id) gets its own three N(0,1) numbers, independent of the
+ * order the atoms are stored or processed in.  mix = the splitmix64 finaliser. */
+static uint64_t lgv_mix(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+void orc_langevin_normals(uint64_t seed, uint64_t step, uint64_t id, double out[3])
+{
+    const uint64_t base = lgv_mix(seed + 0x9E3779B97F4A7C15ull * id);
+    const uint64_t s2 = lgv_mix(base ^ (0xD1B54A32D192ED03ull * (step + 1)));
+    uint64_t r[4];
+    for (int j = 0; j < 4; j++) r[j] = lgv_mix(s2 + 0x9E3779B97F4A7C15ull * (uint64_t)(j + 1));
+    const double two53 = 1.0 / 9007199254740992.0, twopi = 6.283185307179586476925286766559;
+    const double u1 = (double)((r[0] >> 11) + 1) * two53, v2 = (double)(r[1] >> 11) * two53;
+    const double u3 = (double)((r[2] >> 11) + 1) * two53, v4 = (double)(r[3] >> 11) * two53;
+    const double a = sqrt(-2.0 * log(u1)), b = sqrt(-2.0 * log(u3));
+    out[0] = a * cos(twopi * v2);
+    out[1] = a * sin(twopi * v2);
+    out[2] = b * cos(twopi * v4);
+}
+
+/* velocity-Verlet with the O step between the opening half kick and the drift:
+ *   v += (dt/2) f/m ; v = c1 v + c2 sqrt(T/m) xi(seed, step, id) ; x += dt v ; f = F(x) ; v += (dt/2) f/m
+ * c1 = exp(-gamma dt), c2 = sqrt(1 - c1^2); steps are numbered step0, step0 + 1, ...; ids may be NULL (id = i). */
+void orc_verlet_langevin_f64(int32_t N, double *x, double *v, double L, const orc_model64 *m, const orc_atom *atoms,
+                             const double *inv_mass, double dt, int32_t nsteps, int use_cells, int nthreads,
+                             double gamma, double temperature, uint64_t seed, uint64_t step0, const int64_t *ids,
+                             double *epot, double *ekin, double *virial, double *forces_out)
+{
+    double *f = (double *)malloc(sizeof(double) * 3 * (size_t)N);
+    double *e = (double *)malloc(sizeof(double) * (size_t)N);
+    double *w = (double *)malloc(sizeof(double) * (size_t)N);
+    const double c1 = exp(-gamma * dt), c2 = sqrt(1.0 - c1 * c1);
+    verlet_forces(N, x, L, m, atoms, use_cells, nthreads, f, e, w);
+    verlet_observe(N, v, inv_mass, e, w, epot ? epot : NULL, ekin ? ekin : NULL, virial ? virial : NULL);
+    for (int32_t s = 1; s <= nsteps; s++) {
+        for (int32_t i = 0; i < N; i++) {
+            const double im = inv_mass ? inv_mass[i] : 1.0;
+            const double hdtm = 0.5 * dt * im, amp = c2 * sqrt(temperature * im);
+            double xi[3];
+            orc_langevin_normals(seed, step0 + (uint64_t)(s - 1), (uint64_t)(ids ? ids[i] : i), xi);
+            for (int d = 0; d < 3; d++) {
+                double vv = v[3 * i + d] + hdtm * f[3 * i + d];
+                vv = c1 * vv + amp * xi[d];
+                v[3 * i + d] = vv;
+                x[3 * i + d] += dt * vv;
+            }
+        }
+        verlet_forces(N, x, L, m, atoms, use_cells, nthreads, f, e, w);
+        for (int32_t i = 0; i < N; i++) {
+            double hdtm = 0.5 * dt * (inv_mass ? inv_mass[i] : 1.0);
+            for (int d = 0; d < 3; d++) v[3 * i + d] += hdtm * f[3 * i + d];
+        }
+        verlet_observe(N, v, inv_mass, e, w, epot ? epot + s : NULL, ekin ? ekin + s : NULL,
+                       virial ? virial + s : NULL);
+    }
+    if (forces_out) memcpy(forces_out, f, sizeof(double) * 3 * (size_t)N);
+    free(f); free(e); free(w);
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }

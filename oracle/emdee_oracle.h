@@ -102,6 +102,17 @@ void orc_verlet_f64(int32_t N, double *x, double *v, double L, const orc_model64
                     int32_t nsteps, int use_cells, int nthreads,
                     double *epot, double *ekin, double *virial, double *forces_out);
 
+/* Langevin thermostat, build-defined.  Three N(0,1) numbers per (seed, step, atom id) from
+ * splitmix64-finalised counters and Box-Muller; the thermostatted step is
+ *   v += (dt/2) f/m ; v = c1 v + c2 sqrt(T/m) xi ; x += dt v ; f = F(x) ; v += (dt/2) f/m,
+ * c1 = exp(-gamma dt), c2 = sqrt(1 - c1^2).  ids may be NULL (id = index). */
+void orc_langevin_normals(uint64_t seed, uint64_t step, uint64_t id, double out[3]);
+void orc_verlet_langevin_f64(int32_t N, double *x, double *v, double L, const orc_model64 *m,
+                             const orc_atom *atoms, const double *inv_mass, double dt, int32_t nsteps,
+                             int use_cells, int nthreads, double gamma, double temperature, uint64_t seed,
+                             uint64_t step0, const int64_t *ids, double *epot, double *ekin, double *virial,
+                             double *forces_out);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

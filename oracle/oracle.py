@@ -188,5 +188,37 @@ def verlet(x, v, L, mdl, atoms, dt, nsteps, inv_mass=None, use_cells=True, nthre
     return dict(x=x, v=v, f=f, epot=ep, ekin=ek, virial=vir)
 
 
+def langevin_normals(seed, step, ident):
+    """The three N(0,1) numbers of (seed, step, atom id)."""
+    out = (C.c_double * 3)()
+    f = lib().orc_langevin_normals
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+    f.restype = None
+    f(int(seed), int(step), int(ident), out)
+    return np.array(out[:])
+
+
+def verlet_langevin(x, v, L, mdl, atoms, dt, nsteps, gamma, temperature, seed, step0=0, ids=None, inv_mass=None,
+                    use_cells=True, nthreads=0):
+    """velocity-Verlet with the Langevin O step (see emdee_oracle.h). Returns dict with x, v, f, epot, ekin, virial."""
+    x = np.array(x, dtype=np.float64, order="C")
+    v = np.array(v, dtype=np.float64, order="C")
+    atoms = np.ascontiguousarray(atoms, dtype=ATOM_DTYPE)
+    n = x.shape[0]
+    im = None if inv_mass is None else np.ascontiguousarray(inv_mass, dtype=np.float64)
+    idv = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+    ep, ek, vir = (np.empty(nsteps + 1) for _ in range(3))
+    f = np.empty((n, 3))
+    fn = lib().orc_verlet_langevin_f64
+    p = C.c_void_p
+    fn.argtypes = [C.c_int32, p, p, C.c_double, C.POINTER(Model64), p, p, C.c_double, C.c_int32, C.c_int, C.c_int,
+                   C.c_double, C.c_double, C.c_uint64, C.c_uint64, p, p, p, p, p]
+    fn.restype = None
+    fn(n, _ptr(x), _ptr(v), float(L), C.byref(mdl), _ptr(atoms), _ptr(im), float(dt), int(nsteps),
+       int(bool(use_cells)), int(nthreads), float(gamma), float(temperature), int(seed), int(step0), _ptr(idv),
+       _ptr(ep), _ptr(ek), _ptr(vir), _ptr(f))
+    return dict(x=x, v=v, f=f, epot=ep, ekin=ek, virial=vir)
+
+
 def max_threads():
     return lib().orc_max_threads()

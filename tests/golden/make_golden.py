@@ -22,6 +22,7 @@ Run from the repository root:  python tests/golden/make_golden.py
 import importlib.util
 import json
 import os
+import sys
 from fractions import Fraction
 
 import numpy as np
@@ -184,8 +185,65 @@ def make_mix500():
     np.savez_compressed(os.path.join(HERE, "mix500_expected.npz"), L=L, types=types, forces=f, energies=e, virials=w)
 
 
+M64 = (1 << 64) - 1
+
+
+def py_langevin_normals(seed, step, ident):
+    """Independent restatement (Python integers + math) of the thermostat's counter-based normals."""
+    import math
+
+    def mix(z):
+        z &= M64
+        z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & M64
+        z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    base = mix(seed + 0x9E3779B97F4A7C15 * ident)
+    s2 = mix(base ^ ((0xD1B54A32D192ED03 * (step + 1)) & M64))
+    r = [mix(s2 + 0x9E3779B97F4A7C15 * (j + 1)) for j in range(4)]
+    u1, v2 = ((r[0] >> 11) + 1) / 2.0 ** 53, (r[1] >> 11) / 2.0 ** 53
+    u3, v4 = ((r[2] >> 11) + 1) / 2.0 ** 53, (r[3] >> 11) / 2.0 ** 53
+    a, b = math.sqrt(-2.0 * math.log(u1)), math.sqrt(-2.0 * math.log(u3))
+    return [a * math.cos(2.0 * math.pi * v2), a * math.sin(2.0 * math.pi * v2), b * math.cos(2.0 * math.pi * v4)]
+
+
+def numpy_verlet_langevin(x, v, L, rc, rs, eps, sigma, dt, nsteps, gamma, temperature, seed):
+    import math
+    x, v = x.copy(), v.copy()
+    c1 = math.exp(-gamma * dt)
+    c2 = math.sqrt(1.0 - c1 * c1)
+    f, e, w = numpy_all_pairs(x, L, rc, rs, eps, sigma, "cutoff")
+    for s in range(nsteps):
+        xi = np.array([py_langevin_normals(seed, s, i) for i in range(x.shape[0])])
+        v += 0.5 * dt * f
+        v = c1 * v + c2 * math.sqrt(temperature) * xi
+        x += dt * v
+        f, e, w = numpy_all_pairs(x, L, rc, rs, eps, sigma, "cutoff")
+        v += 0.5 * dt * f
+    return x, v, f
+
+
+def make_langevin():
+    cases = [(0, 0, 0), (1234, 0, 0), (1234, 1, 0), (1234, 0, 1), (0x5EED, 99, 863), (2 ** 63 + 5, 10 ** 9, 10 ** 8)]
+    kat = [dict(seed=a, step=b, id=c, normals=py_langevin_normals(a, b, c)) for a, b, c in cases]
+    pos, L = synthetic.fcc_positions(6)
+    vel = synthetic.velocities(pos.shape[0])
+    ones = np.ones(pos.shape[0])
+    x1, v1, f1 = numpy_verlet_langevin(pos, vel, L, 2.5, 2.0, ones, ones, 0.005, 10, 2.0, 0.7, 0x5EED)
+    with open(os.path.join(HERE, "kat_langevin.json"), "w") as fh:
+        json.dump(dict(doc="counter-based normals of the Langevin thermostat (python ints + math) and 10 thermostatted "
+                           "steps of the 864-atom fcc box (gamma 2, T 0.7, seed 0x5EED, dt 0.005): checksums",
+                       normals=kat, x10_sum=float(np.sum(x1)), v10_abs_sum=float(np.abs(v1).sum()),
+                       f10_abs_sum=float(np.abs(f1).sum()), v10_first=v1[0].tolist()), fh, indent=1)
+    print("langevin kat", kat[1]["normals"], "ekin after 10 steps", 0.5 * float(np.sum(v1 * v1)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "langevin":
+        make_langevin()
+        sys.exit(0)
     make_kats()
     make_lj_sample()
     make_fcc864()
     make_mix500()
+    make_langevin()

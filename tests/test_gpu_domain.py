@@ -42,7 +42,10 @@ def _global_box(syn):
     return pos, vel, eps, sigma, float(lengths[0])
 
 
-def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased):
+LANGEVIN = (2.0, 0.7, 0x5EED)     # gamma, T*, seed of the thermostatted case
+
+
+def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased, langevin=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -65,6 +68,8 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased):
                                      torch.from_numpy(mine).to(dev), model, skin=SKIN)
         assert plan.n_ghost > 0
         dd.overlap = bool(phased)      # interior / boundary phases (here around a synchronous, host-staged exchange)
+        if langevin:
+            dd.set_langevin_(*LANGEVIN)
         e0 = dd.totals()
         dd.step_(nsteps, DT, rebuild_every)
         e1 = dd.totals()
@@ -75,13 +80,18 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rebuild_every,phased", [(2, 0, 0), (2, 4, 1), (4, 0, 1), (2, 7, 1)])
-def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every, phased):
+@pytest.mark.parametrize("world,rebuild_every,phased,langevin", [(2, 0, 0, 0), (2, 4, 1, 0), (4, 0, 1, 0), (2, 7, 1, 0),
+                                                                 (2, 3, 1, 1)])
+def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every, phased, langevin):
     nsteps = 25
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every, phased), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every, phased, langevin), nprocs=world,
+             join=True)
     pos, vel, eps, sigma, L = _global_box(emdee.synthetic)
     N = pos.shape[0]
-    ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, nsteps)
+    if langevin:       # noise keyed by global atom id: the decomposed run must draw what the undivided run draws
+        ref = oracle.verlet_langevin(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, nsteps, *LANGEVIN)
+    else:
+        ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, nsteps)
     seen = np.zeros(N, dtype=int)
     for r in range(world):
         d = np.load(tmp_path / ("rank%d.npz" % r))

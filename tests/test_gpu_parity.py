@@ -333,6 +333,62 @@ def test_verlet_fixed_cadence_and_masses(emdee, oracle, dev):
     assert md.nbr_stats()["builds"] == 1 + 6
 
 
+def test_langevin_thermostat(emdee, oracle, dev):
+    """SURVEY.md 8(f) item 4, build-defined: the counter-based generator on the device against the oracle
+    (which tests/test_oracle.py pins on an independent restatement), thermostatted trajectories with masses
+    across call boundaries, run-ahead batches and rebuilds, and relaxation to the target temperature."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(864)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, 864)
+    inv_mass = np.where(np.arange(864) % 3 == 0, 0.5, 1.0)
+    model = E.LennardJonesModel(2.5, 2.0)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev), inv_mass=E.cu(inv_mass, dev))
+    # generator: same integers, libm-level agreement of log / sincos
+    ids = torch.tensor([0, 1, 2, 863, 10 ** 8, 2 ** 40 + 7], dtype=torch.int64, device=dev)
+    for seed, step in ((0, 0), (0x5EED, 99), (2 ** 63 + 5, 10 ** 9)):
+        got = md.langevin_normals(seed, step, ids).cpu().numpy()
+        want = np.array([oracle.langevin_normals(seed, step, int(i)) for i in ids.tolist()])
+        assert np.abs(got - want).max() < 1e-13
+    z = md.langevin_normals(3, 5, torch.arange(200000, device=dev)).cpu().numpy()
+    assert np.abs(z.mean(axis=0)).max() < 0.01 and np.abs(z.std(axis=0) - 1.0).max() < 0.01
+    # trajectories: 1 + 7 + 22 steps in three calls (split kernels, run-ahead batches, a rebuild on the way)
+    gamma, T, seed = 2.0, 0.7, 0x5EED
+    ref = oracle.verlet_langevin(pos, vel, L, oracle.model(2.5, 2.0), atoms, 0.005, 30, gamma, T, seed, inv_mass=inv_mass)
+    md.set_langevin_(gamma, T, seed)
+    for chunk in (1, 7, 22):
+        md.step_(chunk, 0.005)
+    st = md.state()
+    np.testing.assert_allclose(st["positions"].cpu().numpy(), ref["x"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(st["velocities"].cpu().numpy(), ref["v"], rtol=0, atol=1e-8)
+    ep, ek, _ = md.totals()
+    assert ep == pytest.approx(ref["epot"][-1], rel=1e-9) and ek == pytest.approx(ref["ekin"][-1], rel=1e-9)
+    # resuming with first_step and explicit ids (here: a permutation-independent labelling) continues the same run
+    ref2 = oracle.verlet_langevin(ref["x"], ref["v"], L, oracle.model(2.5, 2.0), atoms, 0.005, 6, gamma, T, seed, step0=30,
+                                  ids=np.arange(864) + 1000, inv_mass=inv_mass)
+    md.set_langevin_(gamma, T, seed, first_step=30)
+    md.set_langevin_ids_(torch.arange(864, device=dev) + 1000)
+    md.step_(6, 0.005, rebuild_every=2)
+    np.testing.assert_allclose(md.state()["positions"].cpu().numpy(), ref2["x"], rtol=0, atol=1e-9)
+    # switched off again: plain velocity-Verlet
+    ref3 = oracle.verlet(ref2["x"], ref2["v"], L, oracle.model(2.5, 2.0), atoms, 0.005, 5, inv_mass=inv_mass)
+    md.set_langevin_(0.0, T)
+    md.step_(5, 0.005)
+    np.testing.assert_allclose(md.state()["positions"].cpu().numpy(), ref3["x"], rtol=0, atol=1e-9)
+    # relaxation: a 32k-atom box started at T* = 1 is pulled to 0.4 (kinetic temperature = 2 KE / (3N - 3))
+    pos, L = syn.fcc_positions(20)
+    N = pos.shape[0]
+    big = E.VelocityVerlet(E.cu(pos, dev), E.cu(syn.velocities(N), dev), L, model, E.cu(E.lennard_jones_atoms(1.0, 1.0, N), dev))
+    big.set_langevin_(5.0, 0.4, 77)
+    big.step_(600, 0.005)
+    temps = []
+    for _ in range(5):
+        big.step_(40, 0.005)
+        temps.append(2.0 * big.totals()[1] / (3 * N - 3))
+    assert abs(np.mean(temps) - 0.4) < 0.01
+
+
 def test_verlet_fp32_mixed_precision(emdee, oracle, dev):
     """BASELINE config 4 arithmetic: fp32 storage and pair math, fp64 energy reduction."""
     E = emdee

@@ -239,3 +239,32 @@ def test_empty_and_tiny_inputs(oracle):
     x = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
     f, e, w = oracle.nonbonded_cells(x, 6.0, m, oracle.lj_atoms(1, 1, 2))      # M = 2: de-duplicated stencil
     assert f[0, 0] == pytest.approx(-24.0) and f[1, 0] == pytest.approx(24.0) and w.sum() == pytest.approx(24.0)
+
+
+def test_langevin_generator_and_thermostatted_steps_match_independent_restatement(oracle, emdee_synthetic):
+    """The thermostat is build-defined: pin the oracle's counter-based normals and its
+    thermostatted integrator on the python-int / numpy restatement of tests/golden/make_golden.py."""
+    import json
+    import os
+    from .conftest import ROOT
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_langevin.json")))
+    for c in kat["normals"]:
+        got = oracle.langevin_normals(c["seed"], c["step"], c["id"])
+        assert np.abs(got - np.array(c["normals"])).max() < 1e-15
+    z = np.array([oracle.langevin_normals(11, s, i) for s in range(40) for i in range(250)])
+    assert np.abs(z.mean(axis=0)).max() < 0.05 and np.abs(z.std(axis=0) - 1.0).max() < 0.05
+    syn = emdee_synthetic
+    pos, L = syn.fcc_positions(6)
+    vel = syn.velocities(pos.shape[0])
+    atoms = oracle.lj_atoms(np.ones(pos.shape[0]), np.ones(pos.shape[0]))
+    mdl = oracle.model(2.5, 2.0)
+    for use_cells in (False, True):
+        r = oracle.verlet_langevin(pos, vel, L, mdl, atoms, 0.005, 10, 2.0, 0.7, 0x5EED, use_cells=use_cells)
+        assert float(np.sum(r["x"])) == pytest.approx(kat["x10_sum"], rel=1e-12)
+        assert float(np.abs(r["v"]).sum()) == pytest.approx(kat["v10_abs_sum"], rel=1e-10)
+        assert float(np.abs(r["f"]).sum()) == pytest.approx(kat["f10_abs_sum"], rel=1e-9)
+        assert np.abs(r["v"][0] - np.array(kat["v10_first"])).max() < 1e-11
+    # gamma = 0: c1 = 1, c2 = 0 -> the plain integrator, bit for bit
+    a = oracle.verlet_langevin(pos, vel, L, mdl, atoms, 0.005, 5, 0.0, 0.7, 1)
+    b = oracle.verlet(pos, vel, L, mdl, atoms, 0.005, 5)
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["v"], b["v"])
