@@ -442,6 +442,81 @@ def test_million_atoms_properties(emdee, oracle, dev):
     assert abs(pairs / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 1.5
 
 
+def test_baseline_size_ten_million_atoms(emdee, oracle, dev):
+    """The configuration BASELINE.json's metric is quoted on (fcc 136^3 x 4 = 10,061,824 atoms, fp64, the bench.py
+    default): the whole box against the CPU oracle (OpenMP cell list, a few seconds on the GPU box's host cores),
+    then the MD loop of the bench -- fused steps, run-ahead batches, displacement-triggered rebuilds -- through
+    size-independent properties: momentum and energy conservation, counted pairs."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(136)
+    N = pos.shape[0]
+    assert N == 10061824
+    vel = syn.velocities(N)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    model = E.LennardJonesModel(2.5, 2.0)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev))
+    st = md.state(energies=True, virials=True)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(2.5, 2.0), atoms)
+    assert rel_err(st["forces"].cpu().numpy(), f0) < REL64
+    assert rel_err(st["energies"].cpu().numpy(), e0) < REL64 and rel_err(st["virials"].cpu().numpy(), w0) < REL64
+    del f0, e0, w0
+    ep0, ek0, _ = md.totals()
+    assert ep0 == pytest.approx(float(st["energies"].sum().item()), rel=1e-12)
+    p0 = st["velocities"].sum(dim=0)
+    md.step_(40, 0.005)
+    ep, ek, _ = md.totals()
+    assert abs((ep + ek) / (ep0 + ek0) - 1.0) < 2e-5                 # NVE
+    st = md.state()
+    assert (st["velocities"].sum(dim=0) - p0).abs().max().item() < 1e-6 * np.sqrt(N)      # total momentum
+    assert st["forces"].sum(dim=0).abs().max().item() < 1e-6 * st["forces"].abs().max().item() * np.sqrt(N)
+    stats = md.nbr_stats()
+    assert stats["builds"] >= 4                                       # ~ every 7 steps
+    assert abs(md.count_pairs() / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 1.5
+
+
+def test_target_size_hundred_million_atoms(emdee, dev):
+    """The north-star target size on ONE GPU (fcc 293^3 x 4 = 100,615,028 atoms, fp64, ~40 GB of HBM): no oracle
+    at this size, so size-independent properties only -- Newton's third law over the full list, energy and
+    momentum conservation over displacement-triggered rebuilds, counted pairs against the 10^7-atom value."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(293)
+    N = pos.shape[0]
+    assert N == 100615028
+    vel = syn.velocities(N)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(2.5, 2.0),
+                          E.cu(E.lennard_jones_atoms(1.0, 1.0, N), dev))
+    del pos, vel
+    ep0, ek0, _ = md.totals()
+    st = md.state(positions=False)
+    p0 = st["velocities"].sum(dim=0)
+    fmax = st["forces"].abs().max().item()
+    assert st["forces"].sum(dim=0).abs().max().item() < 1e-6 * fmax * np.sqrt(N)
+    del st
+    md.step_(16, 0.005)
+    ep, ek, _ = md.totals()
+    # The jittered lattice melts during these steps (KE per atom 1.5 -> 0.92) and the relative energy error
+    # swings through +-7e-5 before settling below 1e-5; every box of this family follows the same curve, so
+    # the 10^6-atom box (whose force path is checked against the oracle atom by atom) gives the expected value
+    pos6, L6 = syn.fcc_positions(63)
+    small = E.VelocityVerlet(E.cu(pos6, dev), E.cu(syn.velocities(pos6.shape[0]), dev), L6, E.LennardJonesModel(2.5, 2.0),
+                             E.cu(E.lennard_jones_atoms(1.0, 1.0, pos6.shape[0]), dev))
+    sp0, sk0, _ = small.totals()
+    small.step_(16, 0.005)
+    sp, sk, _ = small.totals()
+    assert (ep0 + ek0) / N == pytest.approx((sp0 + sk0) / pos6.shape[0], rel=1e-5)       # same energy per atom
+    assert ep / N == pytest.approx(sp / pos6.shape[0], rel=1e-4) and ek / N == pytest.approx(sk / pos6.shape[0], rel=1e-3)
+    assert abs(((ep + ek) / (ep0 + ek0) - 1.0) - ((sp + sk) / (sp0 + sk0) - 1.0)) < 3e-6
+    assert abs((ep + ek) / (ep0 + ek0) - 1.0) < 1e-4
+    st = md.state(positions=False, forces=False)
+    assert (st["velocities"].sum(dim=0) - p0).abs().max().item() < 1e-6 * np.sqrt(N)
+    assert md.nbr_stats()["builds"] >= 2
+    assert abs(md.count_pairs() / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 1.5
+    md.close()
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------- edge cases and the direct kernels
 def test_empty_and_tiny_md_states(emdee, oracle, dev):
     E = emdee
