@@ -261,8 +261,10 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         __syncthreads();
         int woff = 0;
         for (int w = 0; w < wv; w++) woff += T.wtot[w];
-        if (tid < NTC) T.off[tid] = woff + inc - my_cnt;
-        if (tid == NTC - 1) T.off[NTC] = woff + inc;
+        // tile slots start at 1: slot 0 is the SENTINEL record (parked far outside the box by the force kernel),
+        // so an index word that was never loaded (all zero bits) and the padding of a row mean the same thing
+        if (tid < NTC) T.off[tid] = 1 + woff + inc - my_cnt;
+        if (tid == NTC - 1) T.off[NTC] = 1 + woff + inc;
     }
     __syncthreads();
     tile_n = T.off[NTC];
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;
     const float rl2 = (float)a.rlist2;
     const float lo2 = rl2 - a.margin, hi2 = rl2 + a.margin;   // margin == 0 for fp32 boxes: the fp32 test is exact
-    // Each group assembles its row in LDS (pre-filled with the SENTINEL slot tile_n, a record the force
+    // Each group assembles its row in LDS (pre-filled with the SENTINEL slot 0, a record the force
     // kernel parks far outside the box, so that it can walk whole blocks with no per-lane bound test) and
     // writes it out as 16-byte, fully coalesced stores instead of scattered 2-byte ones.
     unsigned short *rowbuf = reinterpret_cast<unsigned short *>(s_dyn + (size_t)a.tile_cap * 16 +
@@ -407,8 +409,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     const unsigned ltmask = (1u << gl) - 1u;
     const bool upper = lane >= 32;
     const unsigned ustride = (unsigned)a.stride;
-    const unsigned fill2 = (unsigned)tile_n | ((unsigned)tile_n << 16);
-    const uint4 fill = make_uint4(fill2, fill2, fill2, fill2);
+    const uint4 fill = make_uint4(0, 0, 0, 0);               // sentinel slot 0 (see brick_setup)
     // fp32 test of candidate slot c against atom (p, qi); pairs inside the rounding band are decided with
     // the exact fp64 records (tcr = tile cell x-1 of the candidate's tile row)
     auto in_range_q = [&](const float4 &qi, const float4 &qj, int p, int c, int tcr) -> bool {
@@ -608,8 +609,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         Rec<real> far;
         const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
         far.x = far.y = far.z = big; far.hs = 0;
-        tile[tile_n] = far;
-        if (sizeof(real) == 4) tile_te[tile_n] = 0.f;
+        tile[0] = far;
+        if (sizeof(real) == 4) tile_te[0] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {

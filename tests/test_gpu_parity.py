@@ -442,6 +442,35 @@ def test_million_atoms_properties(emdee, oracle, dev):
     assert abs(pairs / N - 0.5 * (4.0 / 3.0) * np.pi * 2.5 ** 3 * 0.8) < 1.5
 
 
+def test_long_rows_binary_mixture_rc35(emdee, oracle, dev):
+    """BASELINE configs[4] parameters (binary mixture, rc = 3.5 sigma, rs = 3.0) on a box large enough for the
+    LDS-tiled kernels: rows hold ~184 neighbours, i.e. more than the two index blocks a lane prefetches, and
+    straddle the 192-entry block boundary -- some groups of a wavefront need a third block, others must not
+    pick up anything from it."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(24)
+    N = pos.shape[0]
+    pos = pos + 0.3 * (np.random.default_rng(5).random(pos.shape) - 0.5)   # liquid-like spread of the row lengths
+    eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    model = E.LennardJonesModel(3.5, 3.0)
+    tiles = E.nonbonded_computation_tiles(N)
+    f, e, w = zeros(dev, np.float64, N)
+    E.compute_nonbonded_(f, e, w, E.cu(pos, dev), L, tiles, model, E.cu(atoms, dev), 7)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(3.5, 3.0), atoms)
+    assert rel_err(f.cpu().numpy(), f0) < REL64 and rel_err(e.cpu().numpy(), e0) < REL64 and rel_err(w.cpu().numpy(), w0) < REL64
+    st = tiles.stats()
+    assert st["max_count"] > 192 and st["listed"] / N < 192          # rows on both sides of the block boundary
+    # and through the integrator (general-species fused kernel, long rows)
+    vel = syn.velocities(N)
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev))
+    md.step_(12, 0.004)
+    ref = oracle.verlet(pos, vel, L, oracle.model(3.5, 3.0), atoms, 0.004, 12)
+    dx = md.state()["positions"].cpu().numpy() - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+
+
 def test_baseline_size_ten_million_atoms(emdee, oracle, dev):
     """The configuration BASELINE.json's metric is quoted on (fcc 136^3 x 4 = 10,061,824 atoms, fp64, the bench.py
     default): the whole box against the CPU oracle (OpenMP cell list, a few seconds on the GPU box's host cores),
