@@ -139,6 +139,15 @@ struct BrickTables {
     }
 };
 
+// Single-species fp64 force kernels keep only the three coordinate planes in LDS (24 B per record instead of the
+// 32-byte HBM record): with a fixed plane pitch the three reads of a neighbour share one address register and differ
+// in the instruction's immediate offset, and three workgroups fit a CU where the 32-byte tile allows two.
+constexpr int SOA_SLOTS = 2048;                      // plane pitch in records (16 KB per plane)
+template <class Shape, int THREADS>
+static inline size_t brick_force_lds_bytes_soa(int own_cap) {
+    return (size_t)3 * SOA_SLOTS * 8 + BrickTables<Shape, THREADS>::bytes(own_cap);
+}
+
 // bytes of dynamic LDS: force tile = HBM records (+ te plane for fp32); build tile = float4
 template <typename real, class Shape, int THREADS>
 static inline size_t brick_force_lds_bytes(int tile_cap, int own_cap) {
@@ -565,8 +574,10 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // All LDS lives in the dynamic region with 16-byte carve offsets (a static __shared__ in front
     // would shift the base and put the ds_read_b128 gathers off their natural alignment).
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    constexpr bool SOA = UNI && sizeof(real) == 8 && MODE != BRICK_STATS;   // coordinate planes only (see SOA_SLOTS)
     Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
-    const size_t tile_bytes = (size_t)a.tile_cap * sizeof(Rec<real>);
+    real *plane = reinterpret_cast<real *>(s_dyn);                       // SOA: x | y | z, SOA_SLOTS apart
+    const size_t tile_bytes = SOA ? (size_t)3 * SOA_SLOTS * 8 : (size_t)a.tile_cap * sizeof(Rec<real>);
     const size_t te_bytes = sizeof(real) == 4 ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
     float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
     BrickTables<Shape, THREADS> T;
@@ -602,14 +613,16 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         r.x += (real)((sh & 3) - 1) * a.g.len[0];
         r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
         r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
-        tile[s] = r;
+        if (SOA) { plane[s] = r.x; plane[SOA_SLOTS + s] = r.y; plane[2 * SOA_SLOTS + s] = r.z; }
+        else tile[s] = r;
         if (sizeof(real) == 4) tile_te[s] = a.te[gp];
     });
     if (tid == 0) {   // the sentinel record every unused row entry points at: fails r2 < rc2, never NaN
         Rec<real> far;
         const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
         far.x = far.y = far.z = big; far.hs = 0;
-        tile[0] = far;
+        if (SOA) { plane[0] = big; plane[SOA_SLOTS] = big; plane[2 * SOA_SLOTS] = big; }
+        else tile[0] = far;
         if (sizeof(real) == 4) tile_te[0] = 0.f;
     }
 #pragma unroll
@@ -663,10 +676,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         nxt = fetch(o + NGROUPS);
         const int wm = wave_group_max<G>(m);
         real xi, yi, zi, hs_i, te_i;
-        tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
+        if (SOA) { xi = plane[ti]; yi = plane[SOA_SLOTS + ti]; zi = plane[2 * SOA_SLOTS + ti]; hs_i = te_i = 0; }
+        else tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
         real vx = 0, vy = 0, vz = 0, bx = 0, by = 0, bz = 0, imv = 1, nx = 0, ny = 0, nz = 0;
-        if (MODE == BRICK_STEP && have && gl == G - 1) {      // owner lane: its loads fly during the pair loop
+        // (the SOA kernels fetch these after the pair loop instead: 14 registers less = three workgroups per CU)
+        if (MODE == BRICK_STEP && !SOA && have && gl == G - 1) {   // owner lane: its loads fly during the pair loop
             vx = a.vel[p]; vy = a.vel[a.pitch + p]; vz = a.vel[2 * a.pitch + p];
             bx = a.xb[p]; by = a.xb[a.pitch + p]; bz = a.xb[2 * a.pitch + p];
             if (a.inv_mass) imv = a.inv_mass[p];
@@ -680,7 +695,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                 {
                     const int sj = pick16(q, t);
                     real xj, yj, zj, hs_j, te_j;
-                    tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
+                    if (SOA) { xj = plane[sj]; yj = plane[SOA_SLOTS + sj]; zj = plane[2 * SOA_SLOTS + sj]; hs_j = te_j = 0; }
+                    else tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
                     const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const real r2 = dx * dx + dy * dy + dz * dz;
                     if (MODE == BRICK_STATS) {
@@ -723,6 +739,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             if (BITMASK & EMDEE_VIRIALS) w = group_sum_to_last<G>(w);
             if (MODE == BRICK_STEP) {
                 if (have && gl == G - 1) {
+                    if (SOA) {
+                        vx = a.vel[p]; vy = a.vel[a.pitch + p]; vz = a.vel[2 * a.pitch + p];
+                        bx = a.xb[p]; by = a.xb[a.pitch + p]; bz = a.xb[2 * a.pitch + p];
+                        if (a.inv_mass) imv = a.inv_mass[p];
+                        if (a.noise) { nx = a.noise[p]; ny = a.noise[a.pitch + p]; nz = a.noise[2 * a.pitch + p]; }
+                    }
                     const real cm = a.kick_c * imv;
                     vx += cm * fx; vy += cm * fy; vz += cm * fz;
                     if (a.noise) { vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz; }

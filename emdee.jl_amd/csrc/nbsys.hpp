@@ -1,6 +1,7 @@
 // nbsys.hpp -- host-side driver of the cell-ordered system: owns the HBM buffers and enqueues
 // the kernels of kernels.hpp / brick.hpp on the context's stream.  Instantiated for float and double.
 #pragma once
+#include <cstdio>
 
 #include <algorithm>
 #include <cmath>
@@ -295,7 +296,8 @@ struct NbSystem {
     void launch_brick_kernel() {
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
-            if (uniform_atoms) {
+            // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
+            if (uniform_atoms && (sizeof(real) == 4 || tile_cap <= SOA_SLOTS)) {
                 launch_brick_kernel_impl<V, MODE, BM, true>();
                 return;
             }
@@ -306,11 +308,13 @@ struct NbSystem {
     template <class V, int MODE, int BM, bool UNI>
     void launch_brick_kernel_impl() {
         auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM, UNI>;
-        allow_big_lds(kernel, lds_bytes);
+        const size_t lds = (UNI && sizeof(real) == 8 && MODE != BRICK_STATS)
+                               ? brick_force_lds_bytes_soa<typename V::Shape, V::THREADS>(own_cap) : lds_bytes;
+        allow_big_lds(kernel, lds);
         const int phase = (MODE == BRICK_FORCE || MODE == BRICK_STEP) ? force_phase : 0;
         const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
         if (blocks == 0) return;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(V::THREADS), lds_bytes, stream(), brick_args(phase));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(V::THREADS), lds, stream(), brick_args(phase));
     }
 
     template <class V>
@@ -371,6 +375,9 @@ struct NbSystem {
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
             tile_cap = std::max(64, (ctx->host_flags[6] + 1 + 15) / 16 * 16);   // + 1: the sentinel record
             own_cap = std::max(64, (ctx->host_flags[7] + 15) / 16 * 16);
+            if (std::getenv("EMDEE_DEBUG_PLAN"))
+                std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d, own_cap %d, max 3-cell span %d\n", bgrid.nb[0],
+                             bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
             build_alg = (!force_build1 && (V::G == 8 || V::G == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::G) ? 2 : 1;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
             build_variant_threads = V::THREADS; build_variant_g = V::G;
