@@ -273,7 +273,10 @@ def main():
                     out["valu_issue"] = {"kernel": "lj_force_nbr (fused)", "floor_ms": t["issue_floor_ms"],
                                          "avg_launch_ms": force_avg_s * 1e3, "frac": t["issue_floor_ms"] / (force_avg_s * 1e3),
                                          "valu_insts_per_launch": t["valu_insts_per_launch"], "fp64_share": t.get("fp64_share"),
-                                         "model": t.get("model"), "clock_ghz": t.get("clock_ghz"), "source": t.get("source")}
+                                         "model": t.get("model"), "clock_ghz": t.get("clock_ghz"), "source": t.get("source"),
+                                         # same launches inside the counter pass, at the SQ clock measured there
+                                         "profiled_clock_ghz": t.get("profiled_clock_ghz"),
+                                         "frac_at_profiled_clock": t.get("frac_at_profiled_clock")}
             except Exception:
                 pass
         print(json.dumps(out))

@@ -68,6 +68,14 @@ for sub in ("pmc_sq1", "pmc_sq2"):
         for r in csv.DictReader(open(f)):
             if fused(r["Kernel_Name"]):
                 sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+# duration of the same launches inside the counter pass, and the SQ clock they ran at: SQ_BUSY_CYCLES is summed over
+# the 32 shader engines (8 XCDs x 4), so busy cycles / 32 / duration = the engine clock while the kernel was running
+# (checked on the streaming kernels of the same pass: 2.25-2.3 GHz; the fp64 pair kernel holds ~1.9 GHz)
+prof_ns = []
+for f in glob.glob(os.path.join(out, "pmc_sq1", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if fused(r["Kernel_Name"]):
+            prof_ns.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 if sq:
     avg = {k: sum(v) / len(v) for k, v in sq.items()}
     lines = ["rocprofv3 --kernel-trace --pmc <SQ counters, two passes of 8> -- python3 bench.py --steps 12 --warmup 3; N = %d" % N,
@@ -81,10 +89,18 @@ if sq:
     f64 = sum(avg.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("FMA", "MUL", "ADD", "TRANS"))
     lines.append("VALU issue floor = (SQ_INSTS_VALU x 4 + TRANS_F64 x 12 cycles) / %d SIMDs / %.1f GHz = %.3f ms per launch" % (simds, clock_ghz, floor_ms))
     lines.append("fp64 share of VALU instructions: %.2f" % (f64 / insts if insts else 0.0))
+    prof_ms = sum(prof_ns) / len(prof_ns) * 1e-6 if prof_ns else None
+    clock = avg.get("SQ_BUSY_CYCLES", 0.0) / 32.0 / (prof_ms * 1e6) if prof_ms else None
+    floor_clock_ms = floor_ms * clock_ghz / clock if clock else None
+    if clock:
+        lines.append("inside this counter pass the kernel took %.3f ms at SQ_BUSY_CYCLES / 32 / duration = %.3f GHz: issue floor "
+                     "at that clock %.3f ms = %.2f of the measured time" % (prof_ms, clock, floor_clock_ms, floor_clock_ms / prof_ms))
     open(os.path.join(dst, "final_pmc_sq.txt"), "w").write("\n".join(lines) + "\n")
     json.dump(dict(source="profiles/%s/final_pmc_sq.txt (profiles/collect.sh)" % tag, atoms=N, dtype=bench["dtype"],
                    valu_insts_per_launch=insts, valu_trans_f64_per_launch=trans, fp64_share=f64 / insts if insts else None,
-                   simds=simds, clock_ghz=clock_ghz, issue_floor_ms=floor_ms,
+                   simds=simds, clock_ghz=clock_ghz, issue_floor_ms=floor_ms, profiled_ms=prof_ms, profiled_clock_ghz=clock,
+                   issue_floor_at_profiled_clock_ms=floor_clock_ms,
+                   frac_at_profiled_clock=floor_clock_ms / prof_ms if clock else None,
                    model="wave64 VALU instruction = 4 SIMD cycles, TRANS_F64 = 16"),
               open(os.path.join(root, "valu.json"), "w"), indent=1)
     print("valu issue floor: %.3f ms per launch" % floor_ms)
