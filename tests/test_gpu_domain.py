@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _global_box(syn):
+def _global_box(syn, uniform=False):
     pos, gid, lengths = syn.fcc_block((NCELL,) * 3, (0, 0, 0), (NCELL,) * 3)
     order = np.argsort(gid)
     pos = pos[order]
@@ -39,13 +39,15 @@ def _global_box(syn):
     vel -= vel.mean(axis=0)
     vel *= np.sqrt((3 * N - 3) / np.sum(vel * vel))
     eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+    if uniform:            # one species: the engine switches to its single-species kernels (coordinate-plane LDS tile)
+        eps, sigma = np.ones(N), np.ones(N)
     return pos, vel, eps, sigma, float(lengths[0])
 
 
 LANGEVIN = (2.0, 0.7, 0x5EED)     # gamma, T*, seed of the thermostatted case
 
 
-def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased, langevin=0):
+def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased, langevin=0, uniform=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -56,7 +58,7 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased, langevin=
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         syn, domain = pkg.synthetic, pkg.domain
-        pos, vel, eps, sigma, L = _global_box(syn)
+        pos, vel, eps, sigma, L = _global_box(syn, uniform)
         N = pos.shape[0]
         atoms = pkg.lennard_jones_atoms(eps, sigma)
         model = pkg.LennardJonesModel(RC, RS)
@@ -80,13 +82,14 @@ def _worker(rank, world, port, out_dir, nsteps, rebuild_every, phased, langevin=
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rebuild_every,phased,langevin", [(2, 0, 0, 0), (2, 4, 1, 0), (4, 0, 1, 0), (2, 7, 1, 0),
-                                                                 (2, 3, 1, 1)])
-def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every, phased, langevin):
+@pytest.mark.parametrize("world,rebuild_every,phased,langevin,uniform",
+                         [(2, 0, 0, 0, 0), (2, 4, 1, 0, 0), (4, 0, 1, 0, 0), (2, 7, 1, 0, 0), (2, 3, 1, 1, 0), (2, 0, 1, 0, 1),
+                          (4, 5, 0, 1, 1)])
+def test_decomposed_run_matches_oracle(emdee, oracle, tmp_path, world, rebuild_every, phased, langevin, uniform):
     nsteps = 25
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every, phased, langevin), nprocs=world,
-             join=True)
-    pos, vel, eps, sigma, L = _global_box(emdee.synthetic)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nsteps, rebuild_every, phased, langevin, uniform),
+             nprocs=world, join=True)
+    pos, vel, eps, sigma, L = _global_box(emdee.synthetic, uniform)
     N = pos.shape[0]
     if langevin:       # noise keyed by global atom id: the decomposed run must draw what the undivided run draws
         ref = oracle.verlet_langevin(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, nsteps, *LANGEVIN)
