@@ -44,7 +44,7 @@ struct Scanner {
 };
 
 // ---- brick kernel variants (shape, workgroup size, lanes per atom); variant 0 is the default ----
-constexpr int BRICK_VARIANTS = 8;
+constexpr int BRICK_VARIANTS = 9;
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <int V>
@@ -57,6 +57,7 @@ template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static c
 template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
 template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8; };
 template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8; };
+template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
 
 template <class F>
 static inline void with_brick_variant(int v, F &&f) {
@@ -68,6 +69,7 @@ static inline void with_brick_variant(int v, F &&f) {
         case 5: f(BrickVariant<5>{}); break;
         case 6: f(BrickVariant<6>{}); break;
         case 7: f(BrickVariant<7>{}); break;
+        case 8: f(BrickVariant<8>{}); break;
         default: f(BrickVariant<0>{}); break;
     }
 }
@@ -101,6 +103,7 @@ struct NbSystem {
     // path selection
     int path = PATH_BRICK;
     int variant = 0;
+    bool variant_forced = false;          // EMDEE_BRICK_VARIANT given: no automatic choice
     BrickGrid bgrid{};
     int tile_cap = 0, own_cap = 0, row_block = 1;
     int build_alg = 1;                    // k_brick_build ALG (2 = two-phase; 1 when a tile row is too crowded for it)
@@ -120,7 +123,10 @@ struct NbSystem {
 
     NbSystem() {
         if (const char *e = std::getenv("EMDEE_PATH")) path = (std::string(e) == "direct") ? PATH_DIRECT : PATH_BRICK;
-        if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
+        if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) {
+            variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
+            variant_forced = true;
+        }
         if (const char *e = std::getenv("EMDEE_BUILD_ALG")) force_build1 = std::atoi(e) == 1;
         if (const char *e = std::getenv("EMDEE_RUN_AHEAD")) run_ahead = std::max(1, std::min(RUN_AHEAD, std::atoi(e)));
     }
@@ -408,7 +414,15 @@ struct NbSystem {
             double expect = n > 0 ? (4.0 / 3.0) * M_PI * rlist * rlist * rlist * (double)n / vol : 0.0;
             stride = (int)((expect * 1.3 + 24.0) / 16.0 + 1.0) * 16;
         }
+        if (!variant_forced) variant = 0;
         brick_active = (path == PATH_BRICK) && n > 0 && plan_bricks();
+        // A tile too large for two workgroups of the default variant per CU (long cutoffs, dense boxes: rc = 3.5
+        // sigma needs 135 KB) would leave 2 waves per SIMD: take the same bricks with 1024-thread workgroups
+        // (measured on the rc = 3.5 mixture: 116 -> 154 steps/s).
+        if (brick_active && !variant_forced && lds_bytes > LDS_LIMIT / 2) {
+            variant = 8;
+            if (!plan_bricks()) { variant = 0; plan_bricks(); }
+        }
         if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
