@@ -143,9 +143,9 @@ struct BrickTables {
 // 32-byte HBM record): with a fixed plane pitch the three reads of a neighbour share one address register and differ
 // in the instruction's immediate offset, and three workgroups fit a CU where the 32-byte tile allows two.
 constexpr int SOA_SLOTS = 2048;                      // plane pitch in records (16 KB per plane)
-template <class Shape, int THREADS>
+template <typename real, class Shape, int THREADS>
 static inline size_t brick_force_lds_bytes_soa(int own_cap) {
-    return (size_t)3 * SOA_SLOTS * 8 + BrickTables<Shape, THREADS>::bytes(own_cap);
+    return (size_t)3 * SOA_SLOTS * sizeof(real) + BrickTables<Shape, THREADS>::bytes(own_cap);
 }
 
 // bytes of dynamic LDS: force tile = HBM records (+ te plane for fp32); build tile = float4
@@ -574,11 +574,11 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // All LDS lives in the dynamic region with 16-byte carve offsets (a static __shared__ in front
     // would shift the base and put the ds_read_b128 gathers off their natural alignment).
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    constexpr bool SOA = UNI && sizeof(real) == 8 && MODE != BRICK_STATS;   // coordinate planes only (see SOA_SLOTS)
+    constexpr bool SOA = UNI && MODE != BRICK_STATS;   // coordinate planes only (see SOA_SLOTS)
     Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
     real *plane = reinterpret_cast<real *>(s_dyn);                       // SOA: x | y | z, SOA_SLOTS apart
-    const size_t tile_bytes = SOA ? (size_t)3 * SOA_SLOTS * 8 : (size_t)a.tile_cap * sizeof(Rec<real>);
-    const size_t te_bytes = sizeof(real) == 4 ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
+    const size_t tile_bytes = SOA ? (size_t)3 * SOA_SLOTS * sizeof(real) : (size_t)a.tile_cap * sizeof(Rec<real>);
+    const size_t te_bytes = (sizeof(real) == 4 && !SOA) ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
     float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
     BrickTables<Shape, THREADS> T;
     T.carve(s_dyn + tile_bytes + te_bytes);
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
         if (SOA) { plane[s] = r.x; plane[SOA_SLOTS + s] = r.y; plane[2 * SOA_SLOTS + s] = r.z; }
         else tile[s] = r;
-        if (sizeof(real) == 4) tile_te[s] = a.te[gp];
+        if (sizeof(real) == 4 && !SOA) tile_te[s] = a.te[gp];
     });
     if (tid == 0) {   // the sentinel record every unused row entry points at: fails r2 < rc2, never NaN
         Rec<real> far;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         far.x = far.y = far.z = big; far.hs = 0;
         if (SOA) { plane[0] = big; plane[SOA_SLOTS] = big; plane[2 * SOA_SLOTS] = big; }
         else tile[0] = far;
-        if (sizeof(real) == 4) tile_te[0] = 0.f;
+        if (sizeof(real) == 4 && !SOA) tile_te[0] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
@@ -688,7 +688,45 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             if (a.noise) { nx = a.noise[p]; ny = a.noise[a.pitch + p]; nz = a.noise[2 * a.pitch + p]; }
         }
         // one block of 8 G neighbours: lane gl holds entries b0 + gl + t G, t = 0..7, in q
+        // fp32 single-species kernels: two neighbours per lane and pass in packed arithmetic (v_pk_*_f32: the only
+        // way past one fp32 operation per lane and instruction); the coordinate planes deliver (x_a, x_b) pairs
+        // straight into adjacent registers
+        f32x2 pfx = {0.f, 0.f}, pfy = {0.f, 0.f}, pfz = {0.f, 0.f}, pe = {0.f, 0.f}, pw = {0.f, 0.f};
+        constexpr bool PACKED = SOA && sizeof(real) == 4;
+        auto block2 = [&](const uint4 &q, int b0) {
+            if constexpr (PACKED) {
+                const float *pl = reinterpret_cast<const float *>(plane);
+#pragma unroll
+                for (int t = 0; t < EPL; t += 2) {
+                    if (b0 + t * G >= wm) break;              // wave-uniform; the partner entry t + 1 is a sentinel at worst
+                    const int sa = pick16(q, t), sb = pick16(q, t + 1);
+                    const f32x2 dx = f32x2{(float)xi, (float)xi} - f32x2{pl[sa], pl[sb]};
+                    const f32x2 dy = f32x2{(float)yi, (float)yi} - f32x2{pl[SOA_SLOTS + sa], pl[SOA_SLOTS + sb]};
+                    const f32x2 dz = f32x2{(float)zi, (float)zi} - f32x2{pl[2 * SOA_SLOTS + sa], pl[2 * SOA_SLOTS + sb]};
+                    const f32x2 r2 = dx * dx + dy * dy + dz * dz;
+                    const bool ina = r2.x < (float)a.model.rc2, inb = r2.y < (float)a.model.rc2;   // strict test (Q2)
+                    if (ina | inb) {
+                        const f32x2 inv = {fast_rcp(r2.x), fast_rcp(r2.y)};
+                        f32x2 E, W;
+                        lj_interaction_pair2(r2, inv, mdl, f32x2{(float)a.uni_sigma2, (float)a.uni_sigma2},
+                                             f32x2{(float)a.uni_e4, (float)a.uni_e4}, E, W);
+                        E = f32x2{ina ? E.x : 0.f, inb ? E.y : 0.f};
+                        W = f32x2{ina ? W.x : 0.f, inb ? W.y : 0.f};
+                        if (BITMASK & EMDEE_FORCES) {
+                            const f32x2 wr2 = W * inv;
+                            pfx += wr2 * dx; pfy += wr2 * dy; pfz += wr2 * dz;
+                        }
+                        if (BITMASK & EMDEE_ENERGIES) pe += E;
+                        if (BITMASK & EMDEE_VIRIALS) pw += W;
+                    }
+                }
+            }
+        };
         auto block = [&](const uint4 &q, int b0) {
+            if constexpr (PACKED) {
+                block2(q, b0);
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
                 if (b0 + t * G >= wm) break;                  // wave-uniform; entries past a row's end are sentinels
@@ -727,6 +765,10 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             more = make_uint4(0, 0, 0, 0);
             if (b0 + BLK < m) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + BLK + gl * EPL);
             block(q, b0);
+        }
+        if (PACKED) {
+            fx = (real)(pfx.x + pfx.y); fy = (real)(pfy.x + pfy.y); fz = (real)(pfz.x + pfz.y);
+            e = (real)(pe.x + pe.y); w = (real)(pw.x + pw.y);
         }
         if (MODE == BRICK_STATS) {
             if (gl == 0) { st_entries += (unsigned long long)m; st_max = max(st_max, m); }

@@ -74,6 +74,32 @@ __device__ __forceinline__ void lj_interaction_pair(real r2, real inv_r2, const 
     W_out = W * g + E * mgr;
 }
 
+// ---- two pairs per lane in packed fp32 (plain fp32 VALU instructions issue at the fp64 rate on gfx950) ------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the same function as lj_interaction_pair, on two independent pairs at once
+__device__ __forceinline__ void lj_interaction_pair2(f32x2 r2, f32x2 inv_r2, const LJModel<float> &m, f32x2 sigma2, f32x2 e4,
+                                                     f32x2 &E_out, f32x2 &W_out) {
+    const f32x2 s2 = sigma2 * inv_r2;
+    const f32x2 s6 = s2 * s2 * s2;
+    const f32x2 e4s6 = e4 * s6;
+    const f32x2 t = e4s6 * s6;
+    const f32x2 E = t - e4s6;
+    const f32x2 W = 6.0f * (E + t);
+    f32x2 x = r2 * m.idl2 - m.x0;
+    x.x = switch_clamp(x.x);
+    x.y = switch_clamp(x.y);
+    const f32x2 x2 = x * x;
+    const f32x2 u = 1.0f - x;
+    const f32x2 u2 = u * u;
+    const f32x2 g = (u2 * u) * (1.0f + x * (m.k3 + m.k6 * x));
+    const f32x2 mgr = m.c60 * (x2 * u2) * r2;
+    E_out = E * g;
+    W_out = W * g + E * mgr;
+}
+// (double instantiations never call it; the overload keeps `if constexpr` branches well-formed)
+__device__ __forceinline__ void lj_interaction_pair2(f32x2, f32x2, const LJModel<double> &, f32x2, f32x2, f32x2 &, f32x2 &) {}
+
 // Lorentz-Berthelot through the LJAtom encoding: sigma_ij = half_sigma_i + half_sigma_j (:29),
 // 4 eps_ij = twice_sqrt_eps_i * twice_sqrt_eps_j (:30,33)
 template <typename real>

@@ -303,7 +303,7 @@ struct NbSystem {
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
             // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
-            if (uniform_atoms && (sizeof(real) == 4 || tile_cap <= SOA_SLOTS)) {
+            if (uniform_atoms && tile_cap <= SOA_SLOTS) {
                 launch_brick_kernel_impl<V, MODE, BM, true>();
                 return;
             }
@@ -314,8 +314,8 @@ struct NbSystem {
     template <class V, int MODE, int BM, bool UNI>
     void launch_brick_kernel_impl() {
         auto kernel = k_brick<real, typename V::Shape, V::THREADS, V::G, MODE, BM, UNI>;
-        const size_t lds = (UNI && sizeof(real) == 8 && MODE != BRICK_STATS)
-                               ? brick_force_lds_bytes_soa<typename V::Shape, V::THREADS>(own_cap) : lds_bytes;
+        const size_t lds = (UNI && MODE != BRICK_STATS) ? brick_force_lds_bytes_soa<real, typename V::Shape, V::THREADS>(own_cap)
+                                                        : lds_bytes;
         allow_big_lds(kernel, lds);
         const int phase = (MODE == BRICK_FORCE || MODE == BRICK_STEP) ? force_phase : 0;
         const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
