@@ -111,6 +111,7 @@ struct BrickArgs {
     real kick_c, dt, thr2;
     int *trigger;
     const int *guard;          // run-ahead launches: do nothing if the previous step asked for a rebuild
+    int *btab;                 // per-brick tables written once per rebuild (k_brick_tables); NULL = compute them here
     const real *noise;         // Langevin O step between kick and drift: v = lgv_c1 v + noise[p]; NULL = NVE
     real lgv_c1;
     // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
@@ -129,6 +130,9 @@ struct BrickTables {
     int2 *oinfo;   // [own_cap] per own atom {cell-order slot p, (row length or flag) << 16 | tile slot}
     __host__ __device__ static constexpr size_t fixed_ints() { return (NTC + 4) + NTC + NTC + (NOC + 4) + ((NWAVES + 1) & ~1); }
     __host__ __device__ static size_t bytes(int own_cap) { return ((fixed_ints() + 2 * (size_t)own_cap) * 4 + 15) & ~(size_t)15; }
+    // off | gbeg | shift | own are contiguous: that image (+ tile_n, n_own) is what k_brick_tables stores per brick
+    __host__ __device__ static constexpr int image_ints() { return (NTC + 4) + NTC + NTC + (NOC + 4); }
+    __host__ __device__ static constexpr int row_ints() { return (image_ints() + 2 + 3) & ~3; }
     __device__ __forceinline__ void carve(unsigned char *base) {
         off = reinterpret_cast<int *>(base);
         gbeg = off + (NTC + 4);
@@ -191,7 +195,7 @@ __device__ __forceinline__ int pick16(const uint4 &q, int t) {   // t is a compi
 
 // Fills the tile-cell and own-cell tables of this block's brick.  Returns false when the block
 // has nothing to do.  Contains block barriers: every thread of the block must call it.
-template <typename real, class Shape, int THREADS>
+template <typename real, class Shape, int THREADS, bool COMPUTE = false>
 __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const BrickTables<Shape, THREADS> &T, int &bxi,
                                             int &byi, int &bzi, int &tile_n, int &n_own) {
     constexpr int BX = Shape::BX, BY = Shape::BY, BZ = Shape::BZ, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC,
@@ -232,6 +236,18 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         bxi = lb % a.bg.nb[0]; byi = (lb / a.bg.nb[0]) % a.bg.nb[1]; bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
     }
 
+    if (!COMPUTE && a.btab != nullptr) {
+        // the tables of this brick were computed when the list was built (the cell populations are frozen until the
+        // next rebuild): copy the image instead of redoing the scans and the serial own-cell prefix in every launch
+        constexpr int ROW = BrickTables<Shape, THREADS>::row_ints(), IMG = BrickTables<Shape, THREADS>::image_ints();
+        const int *row = a.btab + (size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * ROW;
+        for (int i = tid; i < ROW / 4; i += THREADS)
+            reinterpret_cast<uint4 *>(T.off)[i] = reinterpret_cast<const uint4 *>(row)[i];
+        __syncthreads();
+        tile_n = T.off[IMG];
+        n_own = T.off[IMG + 1];
+        return n_own > 0;
+    }
     int my_cnt = 0;
     if (tid < NTC) {
         const int tx = tid % TX, ty = (tid / TX) % TY, tz = tid / (TX * TY);
@@ -333,6 +349,22 @@ __device__ __forceinline__ void brick_for_each_slot(const BrickTables<Shape, THR
             f(s, tc);
         }
     }
+}
+
+// Once per rebuild: the tables of every brick, stored as the LDS image the other kernels copy in (brick_setup).
+template <typename real, class Shape, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_brick_tables(BrickArgs<real> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    BrickTables<Shape, THREADS> T;
+    T.carve(s_dyn);
+    const int lb = (blockIdx.x % NXCD) * a.bg.per_xcd + blockIdx.x / NXCD;
+    if (lb >= a.bg.nbricks) return;
+    int bxi = 0, byi = 0, bzi = 0, tile_n = 0, n_own = 0;
+    brick_setup<real, Shape, THREADS, true>(a, T, bxi, byi, bzi, tile_n, n_own);   // false also for empty bricks: stored too
+    constexpr int ROW = BrickTables<Shape, THREADS>::row_ints(), IMG = BrickTables<Shape, THREADS>::image_ints();
+    int *row = a.btab + (size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * ROW;
+    for (int i = threadIdx.x; i < IMG; i += THREADS) row[i] = T.off[i];
+    if (threadIdx.x == 0) { row[IMG] = tile_n; row[IMG + 1] = n_own; }
 }
 
 constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetched before the tile is staged

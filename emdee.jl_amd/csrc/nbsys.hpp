@@ -117,6 +117,8 @@ struct NbSystem {
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
     DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags, img, img2;
     DevBuf<unsigned short> nbr16;
+    DevBuf<int> btab;                     // per-brick tables of the current list (k_brick_tables)
+    bool btab_valid = false;
     DevBuf<double> partial, sums;
     DevBuf<unsigned long long> stats;
     Scanner scanner;
@@ -294,6 +296,7 @@ struct NbSystem {
         a.thr2 = (real)(0.25 * skin * skin);
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
+        a.btab = btab_valid ? btab.ptr : nullptr;
         a.noise = lgv_on ? noise.ptr : nullptr; a.lgv_c1 = (real)lgv_c1;
         return a;
     }
@@ -415,6 +418,7 @@ struct NbSystem {
             stride = (int)((expect * 1.3 + 24.0) / 16.0 + 1.0) * 16;
         }
         if (!variant_forced) variant = 0;
+        btab_valid = false;
         brick_active = (path == PATH_BRICK) && n > 0 && plan_bricks();
         // A tile too large for two workgroups of the default variant per CU (long cutoffs, dense boxes: rc = 3.5
         // sigma needs 135 KB) would leave 2 waves per SIMD: take the same bricks with 1024-thread workgroups
@@ -431,6 +435,20 @@ struct NbSystem {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
+                    if (attempt == 0 && !std::getenv("EMDEE_NO_BRICK_TABLES")) {
+                        // tables of every brick, once per rebuild; the build and every force launch copy them in
+                        // (the image depends on the brick shape only: a small workgroup writes it)
+                        constexpr int TT = V::Shape::NTC <= 128 ? 128 : 256;
+                        using BT = BrickTables<typename V::Shape, TT>;
+                        static_assert(BT::row_ints() == BrickTables<typename V::Shape, V::THREADS>::row_ints(), "table row layout");
+                        btab.ensure((size_t)bgrid.nbricks * BT::row_ints());
+                        btab_valid = false;
+                        BrickArgs<real> ta = brick_args();
+                        ta.btab = btab.ptr;
+                        hipLaunchKernelGGL((k_brick_tables<real, typename V::Shape, TT>), dim3(bgrid.per_xcd * NXCD), dim3(TT),
+                                           BT::bytes(0), stream(), ta);
+                        btab_valid = true;
+                    }
                     auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 1>;
                     if constexpr (V::G == 8 || V::G == 16) {
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 2>;
