@@ -380,7 +380,9 @@ constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetch
 constexpr int BUILD2_FIELD = 16;                      // bits per tile row in a lane's bit field
 template <int G> constexpr int build2_max_span() { return BUILD2_FIELD * G; }
 
-template <typename real, class Shape, int THREADS, int G, int ALG = 1>
+// G = lanes that share one atom HERE; GL = lanes per atom of the force kernels, which fixes the lane-major row
+// layout (row_position<GL>) -- the two need not agree.
+template <typename real, class Shape, int THREADS, int G, int ALG = 1, int GL = G>
 __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
                     const int c = k + (k >= BUILD2_FIELD ? cB : cA);
-                    if (e < ustride) rowbuf[row_position<G>(e)] = (unsigned short)c;
+                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)c;
                     e++;
                 }
             }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     const unsigned bits = (half >> gshift) & gmask;
                     if (pass) {
                         const unsigned e = count + __popc(bits & ltmask);
-                        if (e < ustride) rowbuf[row_position<G>(e)] = (unsigned short)c;
+                        if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)c;
                     }
                     count += __popc(bits);
                 }
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     unsigned long long st_entries = 0, st_inside = 0;
     int st_max = 0;
     // The first NPF blocks of a row (128 entries: every row of the LJ boxes) are prefetched.
-    constexpr int NPF = (BLK >= 128) ? 1 : 128 / BLK;
+    constexpr int NPF = (BLK >= 128) ? 1 : 2;   // (G = 4: 64 entries ahead, the rest of the row one block ahead)
     struct IdxBuf { uint4 q[NPF]; };
     auto fetch = [&](int o) {
         IdxBuf b;

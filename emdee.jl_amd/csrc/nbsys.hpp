@@ -49,15 +49,16 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <int V>
 struct BrickVariant;
-template <> struct BrickVariant<0> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<1> { using Shape = BrickShape<3, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<2> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 16; };
-template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8; };
-template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8; };
-template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8; };
-template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8; };
+// G = lanes per atom in the force kernels (and the row layout), GB = lanes per atom in the build kernel
+template <> struct BrickVariant<0> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 4, GB = 8; };
+template <> struct BrickVariant<1> { using Shape = BrickShape<3, 2, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
+template <> struct BrickVariant<2> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
+template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 512, G = 16, GB = G; };
+template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
+template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8, GB = G; };
+template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
+template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8, GB = G; };
+template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8, GB = G; };
 
 template <class F>
 static inline void with_brick_variant(int v, F &&f) {
@@ -387,9 +388,9 @@ struct NbSystem {
             if (std::getenv("EMDEE_DEBUG_PLAN"))
                 std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d, own_cap %d, max 3-cell span %d\n", bgrid.nb[0],
                              bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
-            build_alg = (!force_build1 && (V::G == 8 || V::G == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::G) ? 2 : 1;
+            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? 2 : 1;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
-            build_variant_threads = V::THREADS; build_variant_g = V::G;
+            build_variant_threads = V::THREADS; build_variant_g = V::GB;
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
             // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
@@ -449,11 +450,11 @@ struct NbSystem {
                                            BT::bytes(0), stream(), ta);
                         btab_valid = true;
                     }
-                    auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 1>;
-                    if constexpr (V::G == 8 || V::G == 16) {
-                        if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::G, 2>;
+                    auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 1, V::G>;
+                    if constexpr (V::GB == 8 || V::GB == 16) {
+                        if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
                     }
-                    lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::G);
+                    lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
                     allow_big_lds(kernel, lds_build_bytes);
                     hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(),
                                        brick_args());
