@@ -53,7 +53,7 @@ __device__ __forceinline__ T wave_sum_to_lane63(T v) {
 template <int G, typename T>
 __device__ __forceinline__ T group_sum_to_last(T v) {
     v += dpp_mov<DPP_ROW_SHR1, 0xf, 0xf>(v);
-    v += dpp_mov<DPP_ROW_SHR2, 0xf, 0xf>(v);
+    if (G >= 4) v += dpp_mov<DPP_ROW_SHR2, 0xf, 0xf>(v);
     if (G >= 8) v += dpp_mov<DPP_ROW_SHR4, 0xf, 0xf>(v);
     if (G >= 16) v += dpp_mov<DPP_ROW_SHR8, 0xf, 0xf>(v);
     if (G >= 32) v += dpp_mov<DPP_ROW_BCAST15, 0xa, 0xf>(v);
