@@ -180,12 +180,17 @@ __device__ __forceinline__ unsigned long long group_bits(unsigned long long mask
     return (mask >> base) & ((1ull << G) - 1ull);
 }
 
-// max over the groups of a wavefront of a group-uniform value, as a scalar
+// max over the groups of a wavefront of a group-uniform, non-negative value, as a scalar: DPP row shifts and row
+// broadcasts (no LDS round trips -- the pair loop of a round cannot start before it knows its trip count)
 template <int G>
 __device__ __forceinline__ int wave_group_max(int v) {
-#pragma unroll
-    for (int off = G; off < WAVE; off <<= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
+    if (G <= 1) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, true));
+    if (G <= 2) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR2, 0xf, 0xf, true));
+    if (G <= 4) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR4, 0xf, 0xf, true));
+    if (G <= 8) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR8, 0xf, 0xf, true));
+    if (G <= 16) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xa, 0xf, true));
+    if (G <= 32) v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, true));
+    return __builtin_amdgcn_readlane(v, WAVE - 1);
 }
 
 __device__ __forceinline__ int pick16(const uint4 &q, int t) {   // t is a compile-time constant after unrolling
