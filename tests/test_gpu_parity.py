@@ -406,6 +406,41 @@ def test_verlet_fp32_mixed_precision(emdee, oracle, dev):
     assert ep == pytest.approx(ref["epot"][-1], rel=2e-5) and ek == pytest.approx(ref["ekin"][-1], rel=2e-4)
 
 
+def test_fp32_tiled_kernels_single_species_and_mixture(emdee, oracle, dev):
+    """fp32 on a box large enough for several bricks: the single-species kernels (coordinate planes, packed pair
+    arithmetic, two neighbours per lane) and the general-species kernels against the fp64 oracle within the
+    reference's own bound, and energy conservation of the packed path over rebuilds."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(16)                                  # 16,384 atoms
+    N = pos.shape[0]
+    model = E.LennardJonesModel(2.5, 2.0)
+    for mixture in (False, True):
+        eps, sigma = syn.mixture_parameters(syn.mixture_types(N)) if mixture else (np.ones(N), np.ones(N))
+        atoms = E.lennard_jones_atoms(eps, sigma)
+        f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(2.5, 2.0), atoms)
+        for mask in (1, 7):
+            f, e, w = zeros(dev, np.float32, N)
+            E.compute_nonbonded_(f, e, w, E.cu(pos.astype(np.float32), dev), L, E.nonbonded_computation_tiles(N), model,
+                                 E.cu(atoms, dev), mask)
+            assert np.abs(f.cpu().numpy() - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
+            if mask == 7:
+                assert np.abs(e.cpu().numpy() - e0).max() < 1e-4 and np.abs(w.cpu().numpy() - w0).max() < 1e-3
+    vel = syn.velocities(N)
+    md = E.VelocityVerlet(E.cu(pos.astype(np.float32), dev), E.cu(vel.astype(np.float32), dev), L, model,
+                          E.cu(E.lennard_jones_atoms(1.0, 1.0, N), dev))
+    ep0, ek0, _ = md.totals()
+    md.step_(60, 0.005)
+    ep, ek, _ = md.totals()
+    assert abs((ep + ek) / (ep0 + ek0) - 1.0) < 2e-4 and md.nbr_stats()["builds"] >= 4
+    ref = oracle.verlet(pos, vel, L, oracle.model(2.5, 2.0), E.lennard_jones_atoms(1.0, 1.0, N), 0.005, 10)
+    md2 = E.VelocityVerlet(E.cu(pos.astype(np.float32), dev), E.cu(vel.astype(np.float32), dev), L, model,
+                           E.cu(E.lennard_jones_atoms(1.0, 1.0, N), dev))
+    md2.step_(10, 0.005)
+    dx = md2.state()["positions"].cpu().numpy() - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 2e-4
+
+
 # ------------------------------------------------------------------------- full-size properties
 def test_million_atoms_properties(emdee, oracle, dev):
     """BASELINE configs[1] size (fcc 63^3 x 4 = 1,000,188 atoms, fp64): properties that need no oracle
