@@ -11,11 +11,12 @@
 // LDS read.  The tile of a brick is a pure function of the cell populations, which are frozen
 // between rebuilds, so slots written by the build kernel stay valid for every force pass.
 //
-// Work split inside a workgroup: groups of G lanes share one atom (G = 8 or 16: half / one DPP
-// row per atom, 8 / 4 atoms per wavefront).  Lane l of the group takes neighbours l, l+G, l+2G,
-// ...; the row is stored LANE-MAJOR in blocks of 8 G entries so that those are 8 consecutive
-// uint16 = ONE 16-byte load per lane, issued one atom ahead of the arithmetic.  Per-lane partial
-// sums are combined with DPP row shifts.  Owner-computes, full list: no atomics, no pre-zeroing.
+// Work split inside a workgroup: groups of G lanes share one atom (G = 4 in the default variant: 16 atoms
+// per wavefront, so that the work outside the pair loop is shared by many atoms; 8 or 16 in the tuning
+// variants).  Lane l of the group takes neighbours l, l+G, l+2G, ...; the row is stored LANE-MAJOR in blocks
+// of 8 G entries so that those are 8 consecutive uint16 = ONE 16-byte load per lane, issued one atom ahead
+// of the arithmetic.  Per-lane partial sums are combined with DPP row shifts.  Owner-computes, full list: no
+// atomics, no pre-zeroing.
 //
 // k_brick_build keeps its tile as fp32 positions relative to the brick origin (16 B per record:
 // twice the occupancy of the fp64 tile) and tests r^2 < r_list^2 in fp32 first.  The fp32 result is
