@@ -1,6 +1,6 @@
 # verlet.jl -- velocity-Verlet on the device.  Build-defined: the reference has no integrator
 # (SURVEY.md 8a row a16).  API in EmDee's style: a constructor and `!` mutators.
-export VelocityVerlet, step!, energies, set_langevin!
+export VelocityVerlet, step!, energies, set_langevin!, set_langevin_ids!
 
 mutable struct VelocityVerlet{T}
     handle::Ptr{Cvoid}
@@ -36,6 +36,12 @@ step!(md::VelocityVerlet, nsteps, dt; rebuild_every=0) =
 set_langevin!(md::VelocityVerlet, gamma, temperature; seed=0, first_step=0) =
     check(ccall((:emdee_md_set_langevin, libemdee_hip), Int32, (Ptr{Cvoid}, Float64, Float64, UInt64, UInt64),
                 md.handle, gamma, temperature, seed, first_step))
+
+# int32_t emdee_md_set_langevin_ids(emdee_md *md, const int64_t *ids_dev);
+# Atom ids keying the thermostat's noise (device Int64 vector in caller order); `nothing` = the caller index.
+set_langevin_ids!(md::VelocityVerlet, ids::Union{Nothing,HipArray{Int64,1}}) =
+    check(ccall((:emdee_md_set_langevin_ids, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), md.handle,
+                ids === nothing ? C_NULL : ids.ptr))
 
 # int32_t emdee_md_energies(emdee_md *md, double out[3]);   -> (potential, kinetic, virial sum)
 function energies(md::VelocityVerlet)
