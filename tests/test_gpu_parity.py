@@ -441,6 +441,59 @@ def test_fp32_tiled_kernels_single_species_and_mixture(emdee, oracle, dev):
     assert np.abs(dx - L * np.rint(dx / L)).max() < 2e-4
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_boxes_against_oracle(emdee, oracle, dev, seed):
+    """Seeded random configurations -- box length, density, cutoff, skin, one or two species, clustered or uniform
+    positions -- through the O(N) operator and a few MD steps, against the oracle.  Covers partial bricks, bricks
+    with no own atoms, tiles near and beyond the capacities of the fast paths, and the automatic kernel choices."""
+    E = emdee
+    rng = np.random.default_rng(1000 + seed)
+    rc = float(rng.uniform(1.6, 3.6))
+    rs = rc - float(rng.uniform(0.2, 0.8))
+    skin = float(rng.uniform(0.1, 0.5))
+    rlist = rc + skin
+    L = float(rng.uniform(2.05, 9.0)) * rlist
+    rho = float(rng.choice([0.05, 0.3, 0.6, 0.85, 1.1]))
+    N = int(max(2, min(60000, rho * L ** 3)))
+    pos = rng.uniform(0.0, L, size=(N, 3))
+    if seed % 3 == 0:                       # clustered: half of the atoms in one corner octant (empty and crowded bricks)
+        pos[: N // 2] *= 0.5
+    if seed % 4 == 1:                       # atoms outside the primary box: the operator wraps them
+        pos += L * rng.integers(-2, 3, size=(N, 3))
+    # keep pairs away from the repulsive core, where a 1e-6 relative test of forces ~1e9 says nothing
+    mixture = seed % 2 == 1
+    if mixture:
+        types = rng.integers(0, 2, size=N)
+        eps, sigma = np.where(types == 0, 1.0, 0.5), np.where(types == 0, 1.0, 0.88)
+    else:
+        eps, sigma = np.ones(N), np.full(N, float(rng.choice([1.0, 0.7])))
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    model = E.LennardJonesModel(rc, rs)
+    f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(rc, rs), atoms)
+    finite = np.isfinite(f0).all() and np.abs(f0).max() < 1e12
+    for dtype, tol in ((np.float64, 1e-6),):
+        f, e, w = zeros(dev, dtype, N)
+        tiles = E.nonbonded_computation_tiles(N, skin=skin)
+        E.compute_nonbonded_(f, e, w, E.cu(pos.astype(dtype), dev), L, tiles, model, E.cu(atoms, dev), 7)
+        if finite:
+            assert rel_err(f.cpu().numpy(), f0) < tol and rel_err(e.cpu().numpy(), e0) < tol and rel_err(w.cpu().numpy(), w0) < tol
+        # second call with slightly moved atoms: list reuse or rebuild, same answer as a fresh oracle evaluation
+        pos2 = pos + rng.normal(scale=0.3 * skin, size=pos.shape)
+        f1, e1, w1 = oracle.nonbonded_cells(pos2, L, oracle.model(rc, rs), atoms)
+        E.compute_nonbonded_(f, e, w, E.cu(pos2.astype(dtype), dev), L, tiles, model, E.cu(atoms, dev), 7)
+        if np.isfinite(f1).all() and np.abs(f1).max() < 1e12:
+            assert rel_err(f.cpu().numpy(), f1) < tol and rel_err(e.cpu().numpy(), e1) < tol
+    # a few MD steps from rest on a relaxed-ish subset of cases (no close contacts): trajectory vs oracle
+    if finite and np.abs(f0).max() < 1e4:
+        dt = 1e-3 / max(1.0, np.sqrt(np.abs(f0).max() / 100.0))
+        md = E.VelocityVerlet(E.cu(pos, dev), E.cu(np.zeros_like(pos), dev), L, model, E.cu(atoms, dev), skin=skin)
+        md.step_(12, dt)
+        ref = oracle.verlet(pos, np.zeros_like(pos), L, oracle.model(rc, rs), atoms, dt, 12)
+        dx = md.state()["positions"].cpu().numpy() - ref["x"]
+        assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-8
+        assert md.totals()[0] == pytest.approx(ref["epot"][-1], rel=1e-7, abs=1e-7)
+
+
 # ------------------------------------------------------------------------- full-size properties
 def test_million_atoms_properties(emdee, oracle, dev):
     """BASELINE configs[1] size (fcc 63^3 x 4 = 1,000,188 atoms, fp64): properties that need no oracle
