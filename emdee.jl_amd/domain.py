@@ -365,6 +365,21 @@ class DecomposedVerlet:
             dist.all_reduce(t, group=self.plan.group)
         return tuple(t.tolist())
 
+    def observables(self):
+        """Global temperature and pressure (see VelocityVerlet.observables)."""
+        ep, ek, vir = self.totals()
+        n = self.n_global if self.n_global is not None else self._count_global()
+        v = float(self.plan.L[0] * self.plan.L[1] * self.plan.L[2])
+        return dict(potential=ep, kinetic=ek, virial=vir, temperature=2.0 * ek / max(3 * n - 3, 1),
+                    pressure=(2.0 * ek + vir) / (3.0 * v), density=n / v)
+
+    def _count_global(self):
+        t = torch.tensor([self.md.n_owned], dtype=torch.int64, device="cpu" if self.plan.transport == "host" else self.plan.device)
+        if self.plan.world > 1:
+            dist.all_reduce(t, group=self.plan.group)
+        self.n_global = int(t.item())
+        return self.n_global
+
     def gather_state(self):
         """(gid, positions, velocities, forces) of this rank's owned atoms, caller order = ascending gid."""
         st = self.md.state()

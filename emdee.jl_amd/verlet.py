@@ -115,6 +115,17 @@ class VelocityVerlet:
         _lib.call("emdee_md_energies", self._handle, out)
         return out[0], out[1], out[2]
 
+    def observables(self, volume=None, n_atoms=None):
+        """Instantaneous thermodynamic state from the on-device reductions, reduced units:
+        T = 2 KE / (3 N - 3) (centre-of-mass momentum removed), P = (2 KE + sum W) / (3 V) -- the per-atom virials
+        w_i already hold half of every pair's -r dE/dr, so sum W is the pair virial.  Decomposed runs pass the
+        global volume / atom count and sum the totals over ranks first (DecomposedVerlet.observables)."""
+        ep, ek, vir = self.totals()
+        n = self.n_owned if n_atoms is None else n_atoms
+        v = self.lengths[0] * self.lengths[1] * self.lengths[2] if volume is None else volume
+        return dict(potential=ep, kinetic=ek, virial=vir, temperature=2.0 * ek / max(3 * n - 3, 1),
+                    pressure=(2.0 * ek + vir) / (3.0 * v), density=n / v)
+
     def nbr_stats(self):
         b, l, m, c = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
         _lib.call("emdee_md_nbr_stats", self._handle, C.byref(b), C.byref(l), C.byref(m), C.byref(c))

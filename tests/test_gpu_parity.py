@@ -312,6 +312,10 @@ def test_verlet_100_steps_config0(emdee, oracle, dev, golden):
     assert vir == pytest.approx(g["virial"][100], rel=1e-7)
     assert abs((ep + ek) / (ep0 + ek0) - 1.0) < 1e-4                 # NVE drift bound, SURVEY 8(c)
     assert md.nbr_stats()["builds"] >= 2                             # the displacement trigger fired
+    obs = md.observables()                                           # T and P from the same device reductions
+    assert obs["temperature"] == pytest.approx(2.0 * g["ekin"][100] / (3 * 864 - 3), rel=1e-8)
+    assert obs["pressure"] == pytest.approx((2.0 * g["ekin"][100] + g["virial"][100]) / (3.0 * L ** 3), rel=1e-7)
+    assert obs["density"] == pytest.approx(0.8, rel=1e-12)
 
 
 def test_verlet_fixed_cadence_and_masses(emdee, oracle, dev):
