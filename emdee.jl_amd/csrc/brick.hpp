@@ -687,7 +687,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;     // group inside the block
     unsigned long long st_entries = 0, st_inside = 0;
     int st_max = 0;
-    // The first NPF blocks of a row (128 entries: every row of the LJ boxes) are prefetched.
+    // The first NPF blocks of a row are prefetched one atom ahead (G = 4: 64 of the ~72 entries of an LJ row; the
+    // block after them is requested when the atom's turn starts and arrives while those 64 are being worked on).
     constexpr int NPF = (BLK >= 128) ? 1 : 2;   // (G = 4: 64 entries ahead, the rest of the row one block ahead)
     struct IdxBuf { uint4 q[NPF]; };
     auto fetch = [&](int o) {

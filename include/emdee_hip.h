@@ -183,7 +183,12 @@ int32_t emdee_md_set_state(emdee_md *md, int32_t n_owned, int32_t n_ghost, const
 int32_t emdee_md_get_state(emdee_md *md, void *positions_dev, void *velocities_dev, void *forces_dev,
                            void *energies_dev, void *virials_dev);
 /* nsteps whole steps (n_ghost must be 0: a decomposed run drives the split calls below).
- * rebuild_every > 0: fixed cadence; 0: rebuild when max displacement > skin/2. */
+ * rebuild_every > 0: fixed cadence; 0: rebuild when max displacement > skin/2.
+ * Every inner step is one kernel (force + kick + drift).  With the displacement trigger the steps are
+ * queued a few at a time and read back once per batch; a step queued behind one that asked for a
+ * rebuild checks a device word first and does nothing, so the states produced are exactly those of
+ * stepping one at a time, and results are bitwise reproducible from run to run (deterministic cell
+ * order, owner-computes sums, no floating-point atomics). */
 int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every);
 /* split step for domain-decomposed runs:  kick_drift -> [halo exchange] -> forces -> kick */
 /* v += kick (dt/m) f ; x += dt v (owned).  kick = 0.5: the opening half kick; kick = 1.0 also
