@@ -187,8 +187,8 @@ int32_t emdee_md_get_state(emdee_md *md, void *positions_dev, void *velocities_d
  * Every inner step is one kernel (force + kick + drift).  With the displacement trigger the steps are
  * queued a few at a time and read back once per batch; a step queued behind one that asked for a
  * rebuild checks a device word first and does nothing, so the states produced are exactly those of
- * stepping one at a time, and results are bitwise reproducible from run to run (deterministic cell
- * order, owner-computes sums, no floating-point atomics). */
+ * stepping one at a time, and a given sequence of calls is bitwise reproducible from run to run
+ * (deterministic cell order, owner-computes sums, no floating-point atomics). */
 int32_t emdee_md_step(emdee_md *md, int32_t nsteps, double dt, int32_t rebuild_every);
 /* split step for domain-decomposed runs:  kick_drift -> [halo exchange] -> forces -> kick */
 /* v += kick (dt/m) f ; x += dt v (owned).  kick = 0.5: the opening half kick; kick = 1.0 also

@@ -498,6 +498,34 @@ def test_random_boxes_against_oracle(emdee, oracle, dev, seed):
         assert md.totals()[0] == pytest.approx(ref["epot"][-1], rel=1e-7, abs=1e-7)
 
 
+def test_runs_are_bitwise_reproducible(emdee, dev):
+    """Two independent runs of the same call sequence (own handles, own sorts, own lists) end in identical bits:
+    deterministic cell order, owner-computes sums, no floating-point atomics anywhere on the path.  (A different
+    batching of the steps is the same trajectory only to rounding: the closing and opening half kicks of two calls
+    are two additions where the fused inner step does one.)"""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(20)                                  # 32,000 atoms, 125 bricks
+    N = pos.shape[0]
+    vel = syn.velocities(N)
+    eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+    out = []
+    for atoms, chunks in ((E.lennard_jones_atoms(1.0, 1.0, N), ((1, 7, 52), (1, 7, 52))),
+                          (E.lennard_jones_atoms(eps, sigma), ((60,), (60,)))):
+        states = []
+        for chunk in chunks:
+            md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(2.5, 2.0), E.cu(atoms, dev))
+            for k in chunk:
+                md.step_(k, 0.005)
+            st = md.state(energies=True, virials=True)
+            states.append(st)
+            assert md.nbr_stats()["builds"] >= 5
+        for key in ("positions", "velocities", "forces", "energies", "virials"):
+            assert torch.equal(states[0][key], states[1][key]), key
+        out.append(states[0]["positions"])
+    assert not torch.equal(out[0], out[1])
+
+
 # ------------------------------------------------------------------------- full-size properties
 def test_million_atoms_properties(emdee, oracle, dev):
     """BASELINE configs[1] size (fcc 63^3 x 4 = 1,000,188 atoms, fp64): properties that need no oracle
