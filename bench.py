@@ -89,6 +89,18 @@ def cpu_baseline(pkg, args):
     rate for the benchmark box is the sample rate scaled by the atom-count ratio."""
     from oracle import oracle as orc
     orc.build()
+    if 4 * args.cells ** 3 <= 4000:
+        # BASELINE configs[0] (864 atoms): the reference's own CPU path is a single-threaded all-pairs double loop
+        # (src/nonbonded.jl:122-155); time its restatement the same way, whole benchmark box, no scaling
+        pos, vel, atoms, L = make_box(pkg, args.cells, args.mixture)
+        nsteps = 100
+        t0 = time.perf_counter()
+        orc.verlet(pos, vel, L, orc.model(args.rc, args.rc - 0.5), atoms, args.dt, nsteps, use_cells=False, nthreads=1)
+        per_step = (time.perf_counter() - t0) / (nsteps + 1)
+        return dict(value=1.0 / per_step, unit="steps/s", cores=1, kind="port",
+                    sample="%d velocity-Verlet steps of the benchmark box itself (%d atoms), all-pairs double loop, one "
+                           "thread, fp64 oracle" % (nsteps, pos.shape[0]), sample_steps_per_sec=1.0 / per_step,
+                    sample_atoms=pos.shape[0])
     n = args.cpu_sample_cells
     pos, vel, atoms, L = make_box(pkg, n, args.mixture)
     model = orc.model(args.rc, args.rc - 0.5)

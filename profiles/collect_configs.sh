@@ -3,7 +3,9 @@
 # Usage (on the GPU box, from the repository root):  bash profiles/collect_configs.sh r01
 TAG=${1:-r01}; R=$PWD; OUT=$R/gpurun_out/collect_$TAG; mkdir -p $OUT; : > $OUT/configs.jsonl
 run() { echo "# bench.py $*" >> $OUT/configs.jsonl; timeout -k 10 400 python bench.py "$@" --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err || echo "failed: $*"; }
-run --cells 6 --steps 200 --warmup 20
+# configs[0] with its own CPU baseline (single-threaded all-pairs, as the reference's CPU path)
+echo "# bench.py --cells 6 --steps 200 --warmup 20 (with cpu_baseline)" >> $OUT/configs.jsonl
+timeout -k 10 400 python bench.py --cells 6 --steps 200 --warmup 20 >> $OUT/configs.jsonl 2>> $OUT/configs.err || echo "failed: cells 6"
 run --cells 63 --steps 100 --warmup 20
 run --precision f32 --steps 60 --warmup 10
 run --mixture --rc 3.5 --steps 40 --warmup 10
