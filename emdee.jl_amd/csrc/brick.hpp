@@ -174,13 +174,6 @@ __host__ __device__ __forceinline__ unsigned row_position(unsigned e) {
     return (e & ~(BLK - 1u)) | ((e & (G - 1u)) * EPL) | ((e / G) & (EPL - 1u));
 }
 
-template <int G>
-__device__ __forceinline__ unsigned long long group_bits(unsigned long long mask, int lane) {
-    if (G == 64) return mask;
-    const int base = lane & ~(G - 1);
-    return (mask >> base) & ((1ull << G) - 1ull);
-}
-
 // max over the groups of a wavefront of a group-uniform, non-negative value, as a scalar: DPP row shifts and row
 // broadcasts (no LDS round trips -- the pair loop of a round cannot start before it knows its trip count)
 template <int G>
@@ -384,7 +377,6 @@ constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetch
 // come out ordered lane by lane, i.e. still along the tile rows, so neighbouring entries keep pointing at
 // neighbouring tile slots.
 constexpr int BUILD2_FIELD = 16;                      // bits per tile row in a lane's bit field
-template <int G> constexpr int build2_max_span() { return BUILD2_FIELD * G; }
 
 // G = lanes that share one atom HERE; GL = lanes per atom of the force kernels, which fixes the lane-major row
 // layout (row_position<GL>) -- the two need not agree.

@@ -110,7 +110,6 @@ struct NbSystem {
     int build_alg = 1;                    // k_brick_build ALG (2 = two-phase; 1 when a tile row is too crowded for it)
     bool force_build1 = false;            // EMDEE_BUILD_ALG=1: A/B switch
     size_t lds_bytes = 0, lds_build_bytes = 0;
-    int build_variant_threads = 0, build_variant_g = 0;
     float build_margin = 0.f;
 
     DevBuf<Rec<real>> rec, rec2;
@@ -390,7 +389,6 @@ struct NbSystem {
                              bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
             build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? 2 : 1;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
-            build_variant_threads = V::THREADS; build_variant_g = V::GB;
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
             // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
