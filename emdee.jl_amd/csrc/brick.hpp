@@ -672,7 +672,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // Loop-invariant operands that would otherwise be re-materialised from SGPRs inside every pair
     // iteration (a VOP3 instruction takes one scalar source): keep them in VGPRs.
     LJModel<real> mdl = a.model;
-    asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
+    if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k18));
+    else asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
 
     // ---- own atoms: one G-lane group per atom; the NEXT atom's indices are fetched meanwhile -----
     const int gl = lane & (G - 1);                            // lane inside the group
@@ -774,18 +775,29 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                         st_inside += (b0 + t * G + gl < m && r2 < a.model.rc2) ? 1ull : 0ull;
                     } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
-                        real E, W;
-                        if (UNI) {   // single species: no parameter gather, conversion or mixing per pair
-                            lj_interaction_pair(r2, inv_r2, mdl, a.uni_sigma2, a.uni_e4, E, W);
-                        } else {
-                            lj_interaction(r2, inv_r2, mdl, hs_i, te_i, hs_j, te_j, E, W);
-                        }
-                        if (BITMASK & EMDEE_FORCES) {
-                            const real wr2 = W * inv_r2;      // src/nonbonded.jl:139
+                        if (BITMASK == EMDEE_FORCES) {        // the MD loop's kernels: W / r2 directly (lj_pair.hpp)
+                            real wr2;
+                            if (UNI) {
+                                wr2 = lj_force_over_r2(r2, inv_r2, mdl, a.uni_sigma2, a.uni_e4);
+                            } else {
+                                const real sg = hs_i + hs_j;
+                                wr2 = lj_force_over_r2(r2, inv_r2, mdl, sg * sg, te_i * te_j);
+                            }
                             fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
+                        } else {
+                            real E, W;
+                            if (UNI) {   // single species: no parameter gather, conversion or mixing per pair
+                                lj_interaction_pair(r2, inv_r2, mdl, a.uni_sigma2, a.uni_e4, E, W);
+                            } else {
+                                lj_interaction(r2, inv_r2, mdl, hs_i, te_i, hs_j, te_j, E, W);
+                            }
+                            if (BITMASK & EMDEE_FORCES) {
+                                const real wr2 = W * inv_r2;      // src/nonbonded.jl:139
+                                fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
+                            }
+                            if (BITMASK & EMDEE_ENERGIES) e += E;
+                            if (BITMASK & EMDEE_VIRIALS) w += W;
                         }
-                        if (BITMASK & EMDEE_ENERGIES) e += E;
-                        if (BITMASK & EMDEE_VIRIALS) w += W;
                     }
                 }
             }

@@ -19,6 +19,7 @@ struct LJModel {
     real x0;      // rs2 * idl2
     real c60;     // 60 * idl2
     real k3, k6;  // 3 and 6 as kernel arguments: SGPR operands instead of per-iteration literal moves
+    real k18, k36;  // 6 x the switch polynomial 1 + 3 x + 6 x^2 (force-only kernels fold W's factor 6 into it)
 };
 
 template <typename real>
@@ -28,7 +29,7 @@ static inline LJModel<real> make_model(const emdee_lj_model &m) {
     r.rc2 = (real)m.rc2; r.rs2 = (real)m.rs2; r.idl2 = (real)m.inv_delta2;
     r.x0 = r.rs2 * r.idl2;
     r.c60 = (real)60 * r.idl2;
-    r.k3 = (real)3; r.k6 = (real)6;
+    r.k3 = (real)3; r.k6 = (real)6; r.k18 = (real)18; r.k36 = (real)36;
     return r;
 }
 
@@ -72,6 +73,27 @@ __device__ __forceinline__ void lj_interaction_pair(real r2, real inv_r2, const 
     const real mgr = m.c60 * (x2 * u2) * r2;                           // :40  -r g' = 60 x^2 (1-x)^2 idl2 r2
     E_out = E * g;                                                     // :41
     W_out = W * g + E * mgr;
+}
+
+// Force-only launches need neither E nor W on their own, only (W g + E (-r g')) / r2.  Two products fall out of the
+// algebra: the factor 6 of W = 6 (2 b - a) (a = 4 eps s^-6, b = a s^-6) moves into the constants of the switch
+// polynomial, and -r g' / r2 = 60 idl2 x^2 (1-x)^2 needs no r2 at all.  Same function as lj_interaction_pair
+// followed by (W g + E mgr) * inv_r2, two instructions shorter, different only in rounding.
+template <typename real>
+__device__ __forceinline__ real lj_force_over_r2(real r2, real inv_r2, const LJModel<real> &m, real sigma2, real e4) {
+    const real s2 = sigma2 * inv_r2;
+    const real s6 = s2 * s2 * s2;
+    const real a = e4 * s6;                                            // 4 eps s^-6
+    const real b = a * s6;                                             // 4 eps s^-12
+    const real d = (real)2 * b - a;                                    // W / 6
+    const real em = b - a;                                             // E
+    const real x = switch_clamp(r2 * m.idl2 - m.x0);
+    const real x2 = x * x;
+    const real u = (real)1 - x;
+    const real u2 = u * u;
+    const real g6 = (u2 * u) * (m.k6 + x * (m.k18 + m.k36 * x));       // 6 g = (1-x)^3 (6 + 18 x + 36 x^2)
+    const real q = m.c60 * (x2 * u2);                                  // -r g' / r2
+    return (d * g6) * inv_r2 + em * q;
 }
 
 // ---- two pairs per lane in packed fp32 (plain fp32 VALU instructions issue at the fp64 rate on gfx950) ------
