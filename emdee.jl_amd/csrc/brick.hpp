@@ -741,17 +741,23 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     const bool ina = r2.x < (float)a.model.rc2, inb = r2.y < (float)a.model.rc2;   // strict test (Q2)
                     if (ina | inb) {
                         const f32x2 inv = {fast_rcp(r2.x), fast_rcp(r2.y)};
-                        f32x2 E, W;
-                        lj_interaction_pair2(r2, inv, mdl, f32x2{(float)a.uni_sigma2, (float)a.uni_sigma2},
-                                             f32x2{(float)a.uni_e4, (float)a.uni_e4}, E, W);
-                        E = f32x2{ina ? E.x : 0.f, inb ? E.y : 0.f};
-                        W = f32x2{ina ? W.x : 0.f, inb ? W.y : 0.f};
-                        if (BITMASK & EMDEE_FORCES) {
-                            const f32x2 wr2 = W * inv;
+                        const f32x2 sg2 = {(float)a.uni_sigma2, (float)a.uni_sigma2}, e4v = {(float)a.uni_e4, (float)a.uni_e4};
+                        if (BITMASK == EMDEE_FORCES) {
+                            f32x2 wr2 = lj_force_over_r2_2(r2, inv, mdl, sg2, e4v);
+                            wr2 = f32x2{ina ? wr2.x : 0.f, inb ? wr2.y : 0.f};
                             pfx += wr2 * dx; pfy += wr2 * dy; pfz += wr2 * dz;
+                        } else {
+                            f32x2 E, W;
+                            lj_interaction_pair2(r2, inv, mdl, sg2, e4v, E, W);
+                            E = f32x2{ina ? E.x : 0.f, inb ? E.y : 0.f};
+                            W = f32x2{ina ? W.x : 0.f, inb ? W.y : 0.f};
+                            if (BITMASK & EMDEE_FORCES) {
+                                const f32x2 wr2 = W * inv;
+                                pfx += wr2 * dx; pfy += wr2 * dy; pfz += wr2 * dz;
+                            }
+                            if (BITMASK & EMDEE_ENERGIES) pe += E;
+                            if (BITMASK & EMDEE_VIRIALS) pw += W;
                         }
-                        if (BITMASK & EMDEE_ENERGIES) pe += E;
-                        if (BITMASK & EMDEE_VIRIALS) pw += W;
                     }
                 }
             }

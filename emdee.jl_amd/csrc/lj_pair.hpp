@@ -119,6 +119,25 @@ __device__ __forceinline__ void lj_interaction_pair2(f32x2 r2, f32x2 inv_r2, con
     E_out = E * g;
     W_out = W * g + E * mgr;
 }
+// lj_force_over_r2 on two independent pairs at once
+__device__ __forceinline__ f32x2 lj_force_over_r2_2(f32x2 r2, f32x2 inv_r2, const LJModel<float> &m, f32x2 sigma2, f32x2 e4) {
+    const f32x2 s2 = sigma2 * inv_r2;
+    const f32x2 s6 = s2 * s2 * s2;
+    const f32x2 a = e4 * s6;
+    const f32x2 b = a * s6;
+    const f32x2 d = 2.0f * b - a;
+    const f32x2 em = b - a;
+    f32x2 x = r2 * m.idl2 - m.x0;
+    x.x = switch_clamp(x.x);
+    x.y = switch_clamp(x.y);
+    const f32x2 x2 = x * x;
+    const f32x2 u = 1.0f - x;
+    const f32x2 u2 = u * u;
+    const f32x2 g6 = (u2 * u) * (m.k6 + x * (m.k18 + m.k36 * x));
+    const f32x2 q = m.c60 * (x2 * u2);
+    return (d * g6) * inv_r2 + em * q;
+}
+__device__ __forceinline__ f32x2 lj_force_over_r2_2(f32x2, f32x2, const LJModel<double> &, f32x2, f32x2) { return f32x2{0.f, 0.f}; }
 // (double instantiations never call it; the overload keeps `if constexpr` branches well-formed)
 __device__ __forceinline__ void lj_interaction_pair2(f32x2, f32x2, const LJModel<double> &, f32x2, f32x2, f32x2 &, f32x2 &) {}
 
