@@ -113,6 +113,8 @@ struct BrickArgs {
     int *trigger;
     const int *guard;          // run-ahead launches: do nothing if the previous step asked for a rebuild
     int *btab;                 // per-brick tables written once per rebuild (k_brick_tables); NULL = compute them here
+    // BRICK_FORCE, operator path: results straight into the caller's arrays (caller order, 3 x N / N), no unsort pass
+    real *user_f, *user_e, *user_w;
     const real *noise;         // Langevin O step between kick and drift: v = lgv_c1 v + noise[p]; NULL = NVE
     real lgv_c1;
     // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
@@ -849,11 +851,19 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     if (ex * ex + ey * ey + ez * ez > a.thr2) *a.trigger = 1;
                 }
             } else if (have && gl == G - 1) {
-                if (BITMASK & EMDEE_FORCES) {
-                    a.frc[p] = fx; a.frc[a.pitch + p] = fy; a.frc[2 * a.pitch + p] = fz;
+                if (a.user_f != nullptr || a.user_e != nullptr || a.user_w != nullptr) {
+                    const size_t i = (size_t)a.perm[p];                     // caller index of this atom
+                    // (a tuning variant may run the all-outputs kernel for a narrower request: unselected arrays are NULL)
+                    if ((BITMASK & EMDEE_FORCES) && a.user_f) { a.user_f[3 * i] = fx; a.user_f[3 * i + 1] = fy; a.user_f[3 * i + 2] = fz; }
+                    if ((BITMASK & EMDEE_ENERGIES) && a.user_e) a.user_e[i] = (real)0.5 * e;
+                    if ((BITMASK & EMDEE_VIRIALS) && a.user_w) a.user_w[i] = (real)0.5 * w;
+                } else {
+                    if (BITMASK & EMDEE_FORCES) {
+                        a.frc[p] = fx; a.frc[a.pitch + p] = fy; a.frc[2 * a.pitch + p] = fz;
+                    }
+                    if (BITMASK & EMDEE_ENERGIES) a.en[p] = (real)0.5 * e;   // src/nonbonded.jl:142-145
+                    if (BITMASK & EMDEE_VIRIALS) a.vir[p] = (real)0.5 * w;
                 }
-                if (BITMASK & EMDEE_ENERGIES) a.en[p] = (real)0.5 * e;   // src/nonbonded.jl:142-145
-                if (BITMASK & EMDEE_VIRIALS) a.vir[p] = (real)0.5 * w;
             }
         }
     }

@@ -91,13 +91,21 @@ struct NbrImpl : INbr {
         sys.set_box(lo, len, per);
         sys.set_model(model, sys.skin);
         bool rebuild = !sys.has_list || sys.n_total != N;
-        if (!rebuild) rebuild = sys.user_positions_moved(pos);
+        // list kept: one pass refreshes the records, tests the displacements and re-checks the species (the caller
+        // may have edited atoms); one read-back
+        if (!rebuild) rebuild = sys.refresh_and_check(pos, atoms);
         if (rebuild) sys.load_user(N, 0, pos, nullptr, atoms, nullptr);
-        else { sys.detect_uniform_atoms(atoms); sys.refresh_user(pos, atoms); }   // the caller may have edited atoms
-        sys.compute_forces(bitmask);
-        sys.unsort(nullptr, nullptr, (bitmask & EMDEE_FORCES) ? (real *)forces : nullptr,
-                   (bitmask & EMDEE_ENERGIES) ? (real *)energies : nullptr,
-                   (bitmask & EMDEE_VIRIALS) ? (real *)virials : nullptr);
+        real *uf = (bitmask & EMDEE_FORCES) ? (real *)forces : nullptr, *ue = (bitmask & EMDEE_ENERGIES) ? (real *)energies : nullptr,
+             *uw = (bitmask & EMDEE_VIRIALS) ? (real *)virials : nullptr;
+        if (sys.brick_active) {
+            // the tiled kernels write the caller's arrays themselves (owner lane, caller index from perm)
+            sys.out_f = uf; sys.out_e = ue; sys.out_w = uw;
+            sys.compute_forces(bitmask);
+            sys.out_f = sys.out_e = sys.out_w = nullptr;
+        } else {
+            sys.compute_forces(bitmask);
+            sys.unsort(nullptr, nullptr, uf, ue, uw);
+        }
         EMDEE_HIP_CHECK(hipGetLastError());
     }
     void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) override {

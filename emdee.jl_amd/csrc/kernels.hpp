@@ -339,6 +339,28 @@ __global__ void k_refresh_positions(int n, size_t pitch, GridP<real> g, const in
     store_rec<real>(rec, te, p, x, y, z, a.half_sigma, a.twice_sqrt_eps);
 }
 
+// Operator path, one pass per call: refresh the records (as k_refresh_positions), raise flags[1] if an atom has moved
+// more than sqrt(thr2) since the build (the caller then rebuilds and this refresh is discarded) and flags[5] if the
+// LJAtom array is not one value repeated (which selects between the single-species and the general kernels).
+template <typename real>
+__global__ void k_refresh_check(int n, size_t pitch, GridP<real> g, const int *__restrict__ perm, const real *__restrict__ pos,
+                                const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ xb, Rec<real> *__restrict__ rec,
+                                float *__restrict__ te, real thr2, int *__restrict__ flags) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int i = perm[p];
+    const emdee_lj_atom a = atoms[i], first = atoms[0];
+    const real bx = xb[p], by = xb[pitch + p], bz = xb[2 * pitch + p];
+    const real dx = min_image(pos[3 * (size_t)i] - bx, g.plen[0], g.pinv[0]);
+    const real dy = min_image(pos[3 * (size_t)i + 1] - by, g.plen[1], g.pinv[1]);
+    const real dz = min_image(pos[3 * (size_t)i + 2] - bz, g.plen[2], g.pinv[2]);
+    store_rec<real>(rec, te, p, bx + dx, by + dy, bz + dz, a.half_sigma, a.twice_sqrt_eps);
+    if (dx * dx + dy * dy + dz * dz > thr2) flags[1] = 1;
+    if (__float_as_int(a.half_sigma) != __float_as_int(first.half_sigma) ||
+        __float_as_int(a.twice_sqrt_eps) != __float_as_int(first.twice_sqrt_eps))
+        flags[5] = 1;
+}
+
 // Operator path: has any atom moved more than sqrt(thr2) (minimum image) since the build?
 template <typename real>
 __global__ void k_check_displacement(int n, const int *__restrict__ inv_perm, const real *__restrict__ pos,

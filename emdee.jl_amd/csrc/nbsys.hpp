@@ -297,6 +297,7 @@ struct NbSystem {
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
         a.btab = btab_valid ? btab.ptr : nullptr;
+        a.user_f = out_f; a.user_e = out_e; a.user_w = out_w;
         a.noise = lgv_on ? noise.ptr : nullptr; a.lgv_c1 = (real)lgv_c1;
         return a;
     }
@@ -599,6 +600,9 @@ struct NbSystem {
         return ran;
     }
 
+    // operator path: outputs of the next compute_forces go straight to these caller-order arrays (tiled kernels only)
+    real *out_f = nullptr, *out_e = nullptr, *out_w = nullptr;
+
     void compute_forces(int bitmask, int phase = 0) {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
         EMDEE_REQUIRE(bitmask >= 0 && bitmask <= 7, EMDEE_ERR_INVALID, "bitmask must be a combination of 1|2|4");
@@ -699,6 +703,29 @@ struct NbSystem {
         hipLaunchKernelGGL((k_check_displacement<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
                            inv_perm.ptr, pos, xb.ptr, pitch, grid, thr * thr, flags.ptr + 1);
         return read_rebuild_flag();
+    }
+
+    // operator path, list kept: refresh + displacement test + species test in one pass and one read-back.
+    // Returns true if the list no longer covers the positions (the caller reloads).
+    bool refresh_and_check(const real *pos, const emdee_lj_atom *atoms) {
+        if (n_total == 0) return false;
+        const real thr = (real)(0.5 * skin);
+        EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 1, 0, sizeof(int), stream()));
+        EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));
+        hipLaunchKernelGGL((k_refresh_check<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, pitch,
+                           grid, perm.ptr, pos, atoms, xb.ptr, rec.ptr, te.ptr, thr * thr, flags.ptr);
+        emdee_lj_atom first;
+        EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 6 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        uniform_atoms = false;
+        if (ctx->host_flags[5] == 0 && !std::getenv("EMDEE_NO_UNIFORM")) {
+            uniform_atoms = true;
+            const real sg = (real)first.half_sigma + (real)first.half_sigma;
+            uni_sigma2 = (double)(sg * sg);
+            uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
+        }
+        return ctx->host_flags[1] != 0;
     }
 
     void refresh_user(const real *pos, const emdee_lj_atom *atoms) {
