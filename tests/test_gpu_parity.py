@@ -582,6 +582,15 @@ def test_long_rows_binary_mixture_rc35(emdee, oracle, dev):
     assert rel_err(f.cpu().numpy(), f0) < REL64 and rel_err(e.cpu().numpy(), e0) < REL64 and rel_err(w.cpu().numpy(), w0) < REL64
     st = tiles.stats()
     assert st["max_count"] > 192 and st["listed"] / N < 192          # rows on both sides of the block boundary
+    # narrower requests on the same list: unselected outputs stay untouched (this box runs the 1024-thread variant,
+    # which serves them with its all-outputs kernel and NULL pointers for the arrays that were not asked for)
+    for mask in (2, 4, 5):
+        f2, e2, w2 = zeros(dev, np.float64, N)
+        f2.fill_(7.0); e2.fill_(7.0); w2.fill_(7.0)
+        E.compute_nonbonded_(f2, e2, w2, E.cu(pos, dev), L, tiles, model, E.cu(atoms, dev), mask)
+        assert (rel_err(f2.cpu().numpy(), f0) < REL64) if mask & 1 else bool((f2 == 7.0).all())
+        assert (rel_err(e2.cpu().numpy(), e0) < REL64) if mask & 2 else bool((e2 == 7.0).all())
+        assert (rel_err(w2.cpu().numpy(), w0) < REL64) if mask & 4 else bool((w2 == 7.0).all())
     # and through the integrator (general-species fused kernel, long rows)
     vel = syn.velocities(N)
     md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev))
