@@ -114,3 +114,26 @@ def test_ingest_xyz_forcefield_checkpoint(emdee, tmp_path):
     ing.save_checkpoint(tmp_path / "ck.npz", pos, 2.0 * pos, 17, 10.0)
     x, v, step, L = ing.load_checkpoint(tmp_path / "ck.npz")
     assert (x == pos).all() and (v == 2.0 * pos).all() and step == 17 and L == 10.0
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """The Julia binding cannot be executed here (no Julia in the image): at least keep every `ccall` of
+    emdee.jl_amd/julia/src in step with include/emdee_hip.h -- the symbol exists and takes that many arguments."""
+    import glob
+    import re
+    header = open(os.path.join(ROOT, "include", "emdee_hip.h")).read()
+    protos = {}
+    for m in re.finditer(r"(?:int32_t|const char \*)\s*(emdee_[A-Za-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("void", "") else len(re.split(r",(?![^()]*\))", args))
+    n_calls = 0
+    for path in glob.glob(os.path.join(ROOT, "emdee.jl_amd", "julia", "src", "*.jl")):
+        src = open(path).read()
+        for m in re.finditer(r"ccall\(\(:(emdee_[A-Za-z0-9_]+), libemdee_hip\), (\w+),\s*\((.*?)\),\s", src, re.S):
+            name, types = m.group(1), m.group(3)
+            n = len([t for t in re.split(r",(?![^{}]*\})", types) if t.strip()])
+            assert name in protos, "%s: unknown symbol %s" % (os.path.basename(path), name)
+            assert protos[name] == n, "%s: %s takes %d arguments, the shim passes %d" % (os.path.basename(path), name, protos[name], n)
+            n_calls += 1
+    assert n_calls >= 25
+
