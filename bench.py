@@ -7,11 +7,15 @@ skin 0.3 sigma, neighbour rebuild when any atom has moved skin/2.  A "step" is o
 step of the whole box (fused kick/drift pass + LJ force pass, rebuilds included).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--cells n] [--precision f64|f32]
-                  [--rc 2.5] [--mixture] [--rebuild-every 0] [--no-cpu-baseline]
+                  [--rc 2.5] [--mixture] [--rebuild-every 0] [--no-cpu-baseline] [--scaling strong|weak]
 
 N = 1: fcc 136^3 x 4 = 10,061,824 atoms (the 10^7-atom config the metric is quoted on) on one GPU.
-N > 1 (launched by torch.distributed.run, one rank per GPU): spatial domain decomposition with
-ghost-atom halo exchange over RCCL; weak scaling, every rank owns a 10^7-atom brick.
+N > 1: one rank per GPU, spatial domain decomposition with ghost-atom halo exchange over RCCL.  Either the
+driver starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) or a
+plain `python bench.py --gpus N` starts them itself as a child process (before this process touches the
+GPU).  Default is STRONG scaling (BASELINE configs[2], north_star): the SAME --cells^3 x 4-atom box is cut
+into rank_grid(N) bricks and `value` = steps/s of that box.  `--scaling weak` gives every rank its own
+--cells^3 x 4-atom brick instead (`value` is still steps/s of the -- then N times larger -- box).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (lj_force_nbr) with HIP events
 recorded on its own stream inside the timed region; `cpu_baseline` times the CPU oracle on the host
@@ -67,7 +71,26 @@ def parse_args():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged halo, for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU rehearsal, with --backend gloo)")
     ap.add_argument("--cpu-sample-cells", type=int, default=63)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same --cells^3x4 box on N GPUs (default); weak = one such brick per GPU")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this process has not
+    imported torch or touched the GPU; it only relays the child's output and exit code)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def make_box(pkg, cells, mixture):
@@ -121,8 +144,18 @@ def cpu_baseline(pkg, args):
                 sample_steps_per_sec=1.0 / per_step, sample_atoms=N_sample)
 
 
+def cache_path(args):
+    """Where the 1-GPU line of a configuration is remembered, so that an N-GPU run of the same box on the same
+    checkout can report its strong-scaling efficiency (the driver computes its own from the per-N values)."""
+    key = "c%d_%s_rc%g_skin%g_dt%g%s%s" % (args.cells, args.precision, args.rc, args.skin, args.dt,
+                                          "_mix" if args.mixture else "", "_re%d" % args.rebuild_every if args.rebuild_every else "")
+    return os.path.join(ROOT, ".bench_cache", "onegpu_%s.json" % key)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -131,9 +164,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if args.share_gpu:
         local_rank = 0                     # rehearsal on a 1-GPU box: all ranks on cuda:0 (needs --backend gloo)
     torch.cuda.set_device(local_rank)
@@ -167,7 +198,8 @@ def main():
     else:
         domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
                                                        skin=args.skin, mixture=args.mixture, pkg=pkg,
-                                                       transport="device" if args.backend == "nccl" else "host")
+                                                       transport="device" if args.backend == "nccl" else "host",
+                                                       scaling=args.scaling)
         N_rank, N_total = domain.n_owned, domain.n_global
         run = lambda k: domain.step_(k, args.dt, args.rebuild_every)
         engine = domain.md
@@ -205,7 +237,8 @@ def main():
         tp = torch.tensor([pairs], dtype=torch.int64, device=cdev)
         dist.all_reduce(tp)
         pairs = int(tp.item())
-    ep, ek, vir = engine.totals()
+    ep, ek, vir = (domain if world > 1 else engine).totals()        # decomposed: all-reduced over the ranks
+    N_energy = N_total
 
     steps_per_sec = args.steps / elapsed
     b_step = algorithmic_bytes_per_atom_step(w, rc) * N_total
@@ -222,26 +255,28 @@ def main():
     force_avg_s = force_ms / max(force_launches, 1) * 1e-3
     achieved = b_launch / force_avg_s / 1e9 if force_launches else 0.0
 
+    scaling = args.scaling if world > 1 else "strong"
+    if scaling == "strong":
+        shape = "%d^3x4-atom box" % args.cells + (" cut into %s bricks, one per GPU" % "x".join(str(g) for g in domain.grid) if world > 1 else "")
+    else:
+        shape = "one %d^3x4-atom brick per GPU (%s bricks)" % (args.cells, "x".join(str(g) for g in domain.grid))
     out = {
         "metric": "md_steps_per_sec",
-        # whole-job aggregate: every GPU advances its own 136^3x4-atom brick (weak scaling), so the job does
-        # n_gpus x steps/s brick-steps per second = atom-steps/s / atoms-per-GPU; at n_gpus = 1 this is steps/s
-        "value": steps_per_sec * world,
+        # whole-job figure: velocity-Verlet steps per second of the WHOLE box named in config (all GPUs advance it together)
+        "value": steps_per_sec,
         "unit": "steps/s",
-        "box_steps_per_sec": steps_per_sec,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64" if w == 8 else "f32",
         "data": "synthetic",
-        "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%d^3x4 per GPU), velocity-Verlet dt=%g, skin %g"
-                               % (rc, rs, " binary mixture" if args.mixture else "", N_total, args.cells, args.dt, args.skin),
-                   "atoms": N_total, "atoms_per_gpu": N_rank, "parallelism": parallelism,
-                   "aggregate": "value = n_gpus x steps/s of the decomposed box (one brick of %d^3x4 atoms per GPU)" % args.cells,
+        "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%s), velocity-Verlet dt=%g, skin %g"
+                               % (rc, rs, " binary mixture" if args.mixture else "", N_total, shape, args.dt, args.skin),
+                   "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "parallelism": parallelism,
                    "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
                    "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
         "pair_interactions_per_sec": pairs * steps_per_sec,
@@ -259,11 +294,28 @@ def main():
                        "rebuild(bin+sort+nbr_build)": [rb_ms, rb_launches]},
         "neighbor_list": {"builds_in_timed_region": stats["builds"] - builds0, "listed": stats["listed"],
                           "max_count": stats["max_count"], "capacity": stats["capacity"]},
-        "energy_per_atom": {"potential": ep / N_rank, "kinetic": ek / N_rank},
+        "energy_per_atom": {"potential": ep / N_energy, "kinetic": ek / N_energy},
     }
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args)
+        cp = cache_path(args)
+        if world == 1:
+            try:
+                os.makedirs(os.path.dirname(cp), exist_ok=True)
+                with open(cp, "w") as fh:
+                    json.dump({"value": steps_per_sec, "steps": args.steps, "warmup": args.warmup, "atoms": N_total}, fh)
+            except OSError:
+                pass
+        elif scaling == "strong" and os.path.exists(cp):
+            try:
+                with open(cp) as fh:
+                    one = json.load(fh)
+                if one.get("atoms") == N_total and one.get("value", 0) > 0:
+                    out["efficiency_vs_1gpu"] = steps_per_sec / (world * one["value"])
+                    out["one_gpu_reference"] = one
+            except (OSError, ValueError):
+                pass
         traffic = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic):
             try:

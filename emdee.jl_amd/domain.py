@@ -226,6 +226,22 @@ def _pair_cells(cells, grid):
     return tuple(int(cells) * g for g in grid)
 
 
+def lattice_block(cells, grid, coords, scaling="strong"):
+    """(ncells, block_lo, block_n) of the fcc lattice cells the rank at `coords` of `grid` generates.
+    strong: ONE cells^3 box cut into blocks whose sizes differ by at most one cell per dimension;
+    weak: every rank a cells^3 block of a (g_x cells, g_y cells, g_z cells) lattice."""
+    cells = int(cells)
+    if scaling == "strong":
+        ncells = (cells,) * 3
+        lo = [(c * cells) // g for c, g in zip(coords, grid)]
+        hi = [((c + 1) * cells) // g for c, g in zip(coords, grid)]
+    else:
+        ncells = _pair_cells(cells, grid)
+        lo = [c * cells for c in coords]
+        hi = [(c + 1) * cells for c in coords]
+    return ncells, lo, [h - l for l, h in zip(lo, hi)]
+
+
 class DecomposedVerlet:
     """Velocity-Verlet over a decomposed box: every rank integrates its brick with the HIP engine and
     refreshes its ghosts once per step.  Rebuild (migration + new ghost lists + neighbour list) when
@@ -388,18 +404,21 @@ class DecomposedVerlet:
 
     @classmethod
     def synthetic(cls, cells, world, rank, device, model, precision=torch.float64, skin=0.3, mixture=False,
-                  temperature=1.0, pkg=None, group=None, transport="device"):
-        """Weak-scaling synthetic box: every rank generates (and initially owns) a cells^3-cell fcc brick
-        of the global (g_x cells, g_y cells, g_z cells) lattice.  Velocities get the global centre-of-mass
-        and temperature corrections through two small all-reduces."""
+                  temperature=1.0, pkg=None, group=None, transport="device", scaling="weak"):
+        """Synthetic fcc box of SURVEY.md 8(d), generated in parallel: every rank generates (and initially owns) one
+        block of lattice cells.  scaling = "strong": ONE cells^3-cell box whatever the rank count, cut into
+        rank_grid(world) blocks (sizes differ by at most one lattice cell per dimension; migrate() then hands every
+        atom to the brick that contains it).  scaling = "weak": every rank a cells^3-cell brick of a
+        (g_x cells, g_y cells, g_z cells) lattice.  Velocities get the global centre-of-mass and temperature
+        corrections through two small all-reduces."""
         if pkg is None:
             from __graft_entry__ import load_package
             pkg = load_package()
         syn = pkg.synthetic
         grid = rank_grid(world)
-        ncells = _pair_cells(cells, grid)
         coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
-        pos, gid, lengths = syn.fcc_block(ncells, [c * cells for c in coords], (cells, cells, cells))
+        ncells, block_lo, block_n = lattice_block(cells, grid, coords, scaling)
+        pos, gid, lengths = syn.fcc_block(ncells, block_lo, block_n)
         n_global = 4 * ncells[0] * ncells[1] * ncells[2]
         vel = syn.raw_normals(gid, n_global)
         if mixture:
