@@ -71,6 +71,12 @@ def parse_args():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged halo, for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU rehearsal, with --backend gloo)")
     ap.add_argument("--cpu-sample-cells", type=int, default=63)
+    ap.add_argument("--dd", choices=["native", "torch"], default="native",
+                    help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
+                         "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
+    ap.add_argument("--domains", type=int, default=0,
+                    help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
+                         "process on cuda:0 (device-to-device halo copies instead of RCCL)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same --cells^3x4 box on N GPUs (default); weak = one such brick per GPU")
     return ap.parse_args()
@@ -186,7 +192,9 @@ def main():
     rc, rs = args.rc, args.rc - 0.5
     model = pkg.LennardJonesModel(rc, rs)
 
-    if world == 1:
+    domain = None
+    dd_engine = None
+    if world == 1 and args.domains <= 1:
         pos, vel, atoms, L = make_box(pkg, args.cells, args.mixture)
         N_total = N_rank = pos.shape[0]
         md = pkg.VelocityVerlet(pkg.cu(pos.astype(ndtype), dev), pkg.cu(vel.astype(ndtype), dev), L, model,
@@ -196,16 +204,43 @@ def main():
         engine = md
         parallelism = "single-gpu"
     else:
-        domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
-                                                       skin=args.skin, mixture=args.mixture, pkg=pkg,
-                                                       transport="device" if args.backend == "nccl" else "host",
-                                                       scaling=args.scaling)
+        ndom = world if world > 1 else args.domains
+        if args.dd == "native" or world == 1:
+            # the decomposition inside the library; every rank must get there, or all fall back together
+            ok, err = 1, None
+            try:
+                domain = pkg.DomainDecomposition.synthetic(args.cells, ndom, rank if world > 1 else None, dev, model,
+                                                           precision=tdtype, skin=args.skin, mixture=args.mixture, pkg=pkg,
+                                                           scaling=args.scaling, dist=dist)
+                dd_engine = "native (emdee_dd_*: %s)" % ("RCCL send/recv" if world > 1 else "%d domains in one process, device copies" % ndom)
+            except Exception as e:                                  # noqa: BLE001 -- reported below, then the torch driver runs
+                ok, err = 0, repr(e)
+            if dist is not None:
+                t_ok = torch.tensor([ok], dtype=torch.int32, device=cdev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = int(t_ok.item())
+            if not ok:
+                if world == 1:
+                    raise SystemExit("native decomposition failed: %s" % err)
+                if err is not None:
+                    print("rank %d: native decomposition unavailable (%s); falling back to --dd torch" % (rank, err), file=sys.stderr)
+                domain = None
+        if domain is None:
+            domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
+                                                           skin=args.skin, mixture=args.mixture, pkg=pkg,
+                                                           transport="device" if args.backend == "nccl" else "host",
+                                                           scaling=args.scaling)
+            dd_engine = "torch (emdee.jl_amd/domain.py over torch.distributed %s)" % args.backend
+            engine = domain.md
+            overlap = domain.overlap
+        else:
+            engine = domain.engine(0)
+            overlap = os.environ.get("EMDEE_DD_OVERLAP", "1") != "0"
         N_rank, N_total = domain.n_owned, domain.n_global
         run = lambda k: domain.step_(k, args.dt, args.rebuild_every)
-        engine = domain.md
         parallelism = "dd%s" % "x".join(str(g) for g in domain.grid)
     if args.langevin > 0.0:                # not the BASELINE workload: prices the thermostat (config.thermostat says so)
-        (md if world == 1 else domain).set_langevin_(args.langevin, 1.0, 0x5EED)
+        (md if domain is None else domain).set_langevin_(args.langevin, 1.0, 0x5EED)
 
     def fence():
         if dist is not None:
@@ -232,12 +267,15 @@ def main():
     kd_ms, kd_launches = engine.kernel_time("verlet_kick_drift")
     rb_ms, rb_launches = engine.kernel_time("rebuild")
     stats = engine.nbr_stats()
-    pairs = engine.count_pairs()
+    if domain is not None and world == 1:                # every domain lives in this process
+        pairs = sum(domain.engine(l).count_pairs() for l in range(args.domains))
+    else:
+        pairs = engine.count_pairs()
     if dist is not None:
         tp = torch.tensor([pairs], dtype=torch.int64, device=cdev)
         dist.all_reduce(tp)
         pairs = int(tp.item())
-    ep, ek, vir = (domain if world > 1 else engine).totals()        # decomposed: all-reduced over the ranks
+    ep, ek, vir = (domain if domain is not None else engine).totals()        # decomposed: all-reduced over the ranks
     N_energy = N_total
 
     steps_per_sec = args.steps / elapsed
@@ -248,7 +286,7 @@ def main():
     # force launch (6 w + 4 nbar per atom).
     # A decomposed run splits every pass into an interior and a boundary launch (halo exchange in between):
     # the two launches together carry one pass worth of bytes.
-    split = 2 if (world > 1 and domain.overlap) else 1
+    split = 2 if (domain is not None and overlap) else 1
     fused, plain = fused_launches, plain_launches
     b_launch = (fused * algorithmic_bytes_per_atom_step(w, rc) + plain * force_kernel_bytes_per_atom(w, rc)) \
         * N_rank / split / max(force_launches, 1)
@@ -257,7 +295,7 @@ def main():
 
     scaling = args.scaling if world > 1 else "strong"
     if scaling == "strong":
-        shape = "%d^3x4-atom box" % args.cells + (" cut into %s bricks, one per GPU" % "x".join(str(g) for g in domain.grid) if world > 1 else "")
+        shape = "%d^3x4-atom box" % args.cells + (" cut into %s bricks, one per %s" % ("x".join(str(g) for g in domain.grid), "GPU" if world > 1 else "domain (all on one GPU)") if domain is not None else "")
     else:
         shape = "one %d^3x4-atom brick per GPU (%s bricks)" % (args.cells, "x".join(str(g) for g in domain.grid))
     out = {
@@ -277,6 +315,7 @@ def main():
         "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%s), velocity-Verlet dt=%g, skin %g"
                                % (rc, rs, " binary mixture" if args.mixture else "", N_total, shape, args.dt, args.skin),
                    "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "parallelism": parallelism,
+                   "decomposition": dd_engine,
                    "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
                    "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
         "pair_interactions_per_sec": pairs * steps_per_sec,
@@ -300,14 +339,14 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, args)
         cp = cache_path(args)
-        if world == 1:
+        if world == 1 and domain is None:
             try:
                 os.makedirs(os.path.dirname(cp), exist_ok=True)
                 with open(cp, "w") as fh:
                     json.dump({"value": steps_per_sec, "steps": args.steps, "warmup": args.warmup, "atoms": N_total}, fh)
             except OSError:
                 pass
-        elif scaling == "strong" and os.path.exists(cp):
+        elif world > 1 and scaling == "strong" and os.path.exists(cp):
             try:
                 with open(cp) as fh:
                     one = json.load(fh)

@@ -24,9 +24,11 @@ from .verlet import VelocityVerlet                                              
 from . import synthetic                                                         # noqa: E402
 from . import domain                                                            # noqa: E402
 from . import ingest                                                            # noqa: E402
+from . import dd                                                                # noqa: E402
+from .dd import DomainDecomposition                                             # noqa: E402
 
 __all__ = ["LennardJonesModel", "LennardJonesAtom", "LJAtom", "lennard_jones_atoms", "interaction",
            "FORCES", "ENERGIES", "VIRIALS", "Val", "nonbonded_computation_tiles", "compute_nonbonded_",
            "naively_compute_nonbonded_", "NeighborTiles", "AllPairsTiles", "Cells", "update_cells_",
            "VelocityVerlet", "cu", "to_host", "context_for", "Context", "gpu_available", "synthetic",
-           "EmDeeError", "LITERAL", "CUTOFF", "WAVESIZE", "domain", "ingest"]
+           "EmDeeError", "LITERAL", "CUTOFF", "WAVESIZE", "domain", "ingest", "dd", "DomainDecomposition"]

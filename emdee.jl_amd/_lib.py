@@ -82,6 +82,18 @@ SIGNATURES = {
     "emdee_md_set_langevin": [_p, _dbl, _dbl, C.c_uint64, C.c_uint64],
     "emdee_md_set_langevin_ids": [_p, _p],
     "emdee_md_langevin_normals": [_p, C.c_uint64, C.c_uint64, _p, _i32, _p],
+    "emdee_dd_unique_id": [_p],
+    "emdee_dd_create": [_p, _d3, _i3, _i32, _i32, _p, LJModelC, _dbl, _i32, _pp],
+    "emdee_dd_destroy": [_p],
+    "emdee_dd_set_atoms": [_p, _i32, _i32, _p, _p, _p, _p],
+    "emdee_dd_load": [_p],
+    "emdee_dd_step": [_p, _i32, _dbl, _i32],
+    "emdee_dd_energies": [_p, _d3],
+    "emdee_dd_counts": [_p, _i32, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)],
+    "emdee_dd_get_state": [_p, _i32, _p, _p, _p, _p],
+    "emdee_dd_engine": [_p, _i32, _pp],
+    "emdee_dd_set_langevin": [_p, _dbl, _dbl, C.c_uint64, C.c_uint64],
+    "emdee_dd_stats": [_p, C.POINTER(_i64)],
     "emdee_last_error": [],
 }
 _RESTYPES = {"emdee_last_error": C.c_char_p}

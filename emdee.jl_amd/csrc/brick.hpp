@@ -105,7 +105,10 @@ struct BrickArgs {
     unsigned long long *stats; // BRICK_STATS: [0] entries, [1] max row, [2] in-cutoff entries
     int phase;                 // 0: every brick; 1: bricks whose tile has no ghost cell; 2: the others
     // BRICK_STEP only
-    real *vel;                 // SoA planes, updated in place
+    real *vel;                 // SoA planes of the current velocities (read)
+    real *vel_next;            // ... and of the next ones (written): velocities ping-pong with the positions, so a
+                               // step whose results must be discarded (decomposed runs: a neighbour asked for a
+                               // rebuild while the interior bricks were already integrating) leaves no trace
     const real *xb;            // positions at the last build (rebuild trigger)
     const real *inv_mass;      // may be NULL
     Rec<real> *rec_next;       // position buffer of the next step
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     const real cm = a.kick_c * imv;
                     vx += cm * fx; vy += cm * fy; vz += cm * fz;
                     if (a.noise) { vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz; }
-                    a.vel[p] = vx; a.vel[a.pitch + p] = vy; a.vel[2 * a.pitch + p] = vz;
+                    a.vel_next[p] = vx; a.vel_next[a.pitch + p] = vy; a.vel_next[2 * a.pitch + p] = vz;
                     Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
                     r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz;
                     a.rec_next[p] = r;

@@ -1,6 +1,9 @@
 // capi.hip -- the extern "C" boundary declared in include/emdee_hip.h: context, memory and
 // precision dispatch.  No template code here; see impl.hpp.
+#include <dlfcn.h>
+
 #include <mutex>
+#include <vector>
 
 #include "iface.hpp"
 
@@ -25,6 +28,7 @@ using namespace emdee;
 struct emdee_cells { emdee_ctx *ctx; ICells *impl; };
 struct emdee_nbr   { emdee_ctx *ctx; INbr *impl; };
 struct emdee_md    { emdee_ctx *ctx; IMd *impl; };
+struct emdee_dd    { emdee_ctx *ctx; IDd *impl; std::vector<emdee_md *> engines; };
 
 #define REQUIRE_PTR(p, what) EMDEE_REQUIRE((p) != nullptr, EMDEE_ERR_INVALID, what " is NULL")
 #define REQUIRE_PRECISION(p) EMDEE_REQUIRE(valid_precision(p), EMDEE_ERR_INVALID, "precision must be EMDEE_F32 (4) or EMDEE_F64 (8), got %d", (int)(p))
@@ -390,6 +394,93 @@ int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, co
         EMDEE_REQUIRE(n >= 0 && (n == 0 || (ids_dev && out_dev)), EMDEE_ERR_INVALID, "langevin_normals: bad arguments");
         md->impl->langevin_normals(seed, step, ids_dev, n, out_dev);
     });
+}
+
+// ---------------------------------------------------------------- domain decomposition
+int32_t emdee_dd_unique_id(uint8_t out[128]) {
+    return guarded([&] {
+        REQUIRE_PTR(out, "out");
+        // resolved here (not through dd.hpp) so that this translation unit stays free of template code
+        void *h = nullptr;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        EMDEE_REQUIRE(h != nullptr, EMDEE_ERR_INVALID, "librccl.so.1 not found (%s)", dlerror());
+        typedef struct { char internal[128]; } Id;
+        auto get = reinterpret_cast<int (*)(Id *)>(dlsym(h, "ncclGetUniqueId"));
+        EMDEE_REQUIRE(get != nullptr, EMDEE_ERR_INVALID, "librccl: missing symbol ncclGetUniqueId");
+        Id id;
+        const int r = get(&id);
+        EMDEE_REQUIRE(r == 0, EMDEE_ERR_HIP, "ncclGetUniqueId failed with code %d", r);
+        memcpy(out, &id, 128);
+    });
+}
+int32_t emdee_dd_create(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int32_t rank_first, int32_t n_local,
+                        const uint8_t *unique_id, emdee_lj_model model, double skin, int32_t precision, emdee_dd **out) {
+    return guarded([&] {
+        REQUIRE_PTR(ctx, "ctx");
+        REQUIRE_PTR(out, "out");
+        REQUIRE_PTR(len, "len");
+        REQUIRE_PTR(grid, "grid");
+        REQUIRE_PRECISION(precision);
+        *out = nullptr;
+        use_device(ctx);
+        IDd *impl = precision == EMDEE_F32 ? Factory<float>::dd(ctx, len, grid, rank_first, n_local, unique_id, model, skin)
+                                           : Factory<double>::dd(ctx, len, grid, rank_first, n_local, unique_id, model, skin);
+        emdee_dd *dd = new emdee_dd{ctx, impl, {}};
+        for (int l = 0; l < n_local; l++) dd->engines.push_back(new emdee_md{ctx, impl->engine(l)});
+        *out = dd;
+    });
+}
+int32_t emdee_dd_destroy(emdee_dd *dd) {
+    return guarded([&] {
+        if (!dd) return;
+        (void)hipSetDevice(dd->ctx->device);
+        for (emdee_md *m : dd->engines) delete m;          // borrowed views: the integrators belong to impl
+        delete dd->impl;
+        delete dd;
+    });
+}
+int32_t emdee_dd_set_atoms(emdee_dd *dd, int32_t local, int32_t n, const void *positions_dev, const void *velocities_dev,
+                           const emdee_lj_atom *atoms_dev, const int64_t *gids_dev) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->set_atoms(local, n, positions_dev, velocities_dev, atoms_dev, gids_dev); });
+}
+int32_t emdee_dd_load(emdee_dd *dd) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->load(); });
+}
+int32_t emdee_dd_step(emdee_dd *dd, int32_t nsteps, double dt, int32_t rebuild_every) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->step(nsteps, dt, rebuild_every); });
+}
+int32_t emdee_dd_energies(emdee_dd *dd, double out[3]) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->energies(out); });
+}
+int32_t emdee_dd_counts(emdee_dd *dd, int32_t local, int64_t *n_global, int32_t *n_owned, int32_t *n_ghost) {
+    return guarded([&] {
+        REQUIRE_PTR(dd, "dd");
+        if (n_global) *n_global = dd->impl->n_atoms_global();
+        if (n_owned) *n_owned = dd->impl->n_owned(local);
+        if (n_ghost) *n_ghost = dd->impl->n_ghost(local);
+    });
+}
+int32_t emdee_dd_get_state(emdee_dd *dd, int32_t local, int64_t *gids_dev, void *positions_dev, void *velocities_dev,
+                           void *forces_dev) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->get_state(local, gids_dev, positions_dev, velocities_dev, forces_dev); });
+}
+int32_t emdee_dd_engine(emdee_dd *dd, int32_t local, emdee_md **out) {
+    return guarded([&] {
+        REQUIRE_PTR(dd, "dd");
+        REQUIRE_PTR(out, "out");
+        EMDEE_REQUIRE(local >= 0 && local < (int32_t)dd->engines.size(), EMDEE_ERR_INVALID, "emdee_dd_engine: local domain out of range");
+        *out = dd->engines[local];
+    });
+}
+int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, uint64_t seed, uint64_t first_step) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->set_langevin(gamma, temperature, seed, first_step); });
+}
+int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->stats(out); });
 }
 
 }  // extern "C"

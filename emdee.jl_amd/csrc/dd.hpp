@@ -1,0 +1,817 @@
+// dd.hpp -- spatial domain decomposition behind the C ABI (emdee_dd_*).
+//
+// One emdee_dd object drives the domains that live in THIS process:
+//   * production: one process per GPU, one domain per process, messages over RCCL (xGMI) -- ncclSend/ncclRecv
+//     grouped per step on a communication stream of its own, resolved from librccl at run time;
+//   * validation on a one-GPU box: all domains of the decomposition in one process on one device, messages as
+//     device-to-device copies between the domains' streams (same code path up to the transport call).
+//
+// A velocity-Verlet step of a decomposed box is, per domain and with no host round trip:
+//   pack ghost-source positions (+ this domain's rebuild request) -> exchange, in flight on the communication
+//   stream || fused force + kick + drift over the INTERIOR bricks (their LDS tile holds no ghost cell)
+//   -> unpack ghosts, OR of all requests -> the same kernel over the BOUNDARY bricks.
+// The rebuild decision rides on the halo messages: with at most three bricks per dimension every domain is a
+// neighbour of every other one, so the requests of a step reach everybody with the positions they refer to.
+// A step whose positions were flagged does nothing (device-side guard words), as do all steps queued behind
+// it; the host reads the words back once per batch of queued steps, rewinds to the flagged step and rebuilds:
+// migration (only atoms that left their brick travel), new ghost lists, re-sort, neighbour list.
+#pragma once
+
+#include <dlfcn.h>
+
+#include <memory>
+#include <vector>
+
+#include "dd_kernels.hpp"
+#include "impl.hpp"
+
+namespace emdee {
+
+// ------------------------------------------------------------------------------------ RCCL, resolved at run time
+// (libemdee_hip.so carries no link-time dependency on librccl: single-GPU users never load it, and inside a
+// PyTorch process the already-loaded librccl.so.1 is the one that is found)
+struct RcclApi {
+    typedef struct { char internal[128]; } UniqueId;
+    typedef void *Comm;
+    void *handle = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static constexpr int kChar = 0, kFloat64 = 8, kSum = 0;   // ncclInt8 / ncclFloat64 / ncclSum (rccl.h)
+
+    static RcclApi &get() {
+        static RcclApi api;
+        return api;
+    }
+    void load() {
+        if (handle) return;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        EMDEE_REQUIRE(handle != nullptr, EMDEE_ERR_INVALID, "librccl.so.1 not found (%s)", dlerror());
+        auto sym = [&](const char *name) {
+            void *p = dlsym(handle, name);
+            EMDEE_REQUIRE(p != nullptr, EMDEE_ERR_INVALID, "librccl: missing symbol %s", name);
+            return p;
+        };
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    }
+};
+#define EMDEE_RCCL_CHECK(expr)                                                                       \
+    do {                                                                                             \
+        int r_ = (expr);                                                                             \
+        if (r_ != 0) {                                                                               \
+            ::emdee::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                         \
+                               ::emdee::RcclApi::get().GetErrorString(r_));                          \
+            throw ::emdee::Failure{EMDEE_ERR_HIP};                                                   \
+        }                                                                                            \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ geometry (host)
+struct DdGeom {
+    double L[3], halo;
+    int grid[3], world;
+    int rank, coords[3];
+    double width[3], lo[3], hi[3], local_lo[3], local_len[3];
+    int cut[3], periodic[3];
+    int ndirs = 0;
+    int dir[DD_MAX_DIRS][3], dir_rank[DD_MAX_DIRS];
+    double dir_shift[DD_MAX_DIRS][3];
+    int npeers = 0;
+    int peers[DD_MAX_PEERS];             // distinct neighbour ranks, ascending
+    int ghost_nbins = 0;
+    int dir_of_bin[DD_MAX_DIRS];         // send-list bins: directions sorted by (destination rank, direction)
+    int bin_of_dir[DD_MAX_DIRS];
+    int peer_bin_lo[DD_MAX_PEERS + 2];   // bins of peer p: [peer_bin_lo[p], peer_bin_lo[p+1])
+
+    int peer_index(int r) const {
+        for (int p = 0; p < npeers; p++)
+            if (peers[p] == r) return p;
+        return -1;
+    }
+
+    void init(const double L_[3], const int grid_[3], double halo_, int rank_) {
+        halo = halo_; rank = rank_;
+        world = grid_[0] * grid_[1] * grid_[2];
+        for (int d = 0; d < 3; d++) { L[d] = L_[d]; grid[d] = grid_[d]; }
+        coords[0] = rank % grid[0]; coords[1] = (rank / grid[0]) % grid[1]; coords[2] = rank / (grid[0] * grid[1]);
+        for (int d = 0; d < 3; d++) {
+            width[d] = L[d] / grid[d];
+            lo[d] = coords[d] * width[d];
+            hi[d] = lo[d] + width[d];
+            cut[d] = grid[d] > 1;
+            EMDEE_REQUIRE(grid[d] <= 3, EMDEE_ERR_INVALID,
+                          "emdee_dd: at most 3 bricks per dimension (every domain must neighbour every other one)");
+            if (cut[d]) EMDEE_REQUIRE(halo <= width[d], EMDEE_ERR_INVALID, "halo %g exceeds the brick width %g along dimension %d", halo, width[d], d);
+            else EMDEE_REQUIRE(2.0 * halo <= L[d], EMDEE_ERR_INVALID, "cutoff + skin exceeds half the periodic length along dimension %d", d);
+            local_lo[d] = cut[d] ? lo[d] - halo : 0.0;
+            local_len[d] = cut[d] ? width[d] + 2 * halo : L[d];
+            periodic[d] = cut[d] ? 0 : 1;
+        }
+        // 26 directions in the fixed order of domain.py (x fastest), only cut dimensions may be non-zero
+        ndirs = 0;
+        for (int sz = -1; sz <= 1; sz++)
+            for (int sy = -1; sy <= 1; sy++)
+                for (int sx = -1; sx <= 1; sx++) {
+                    const int s[3] = {sx, sy, sz};
+                    if (sx == 0 && sy == 0 && sz == 0) continue;
+                    bool ok = true;
+                    for (int d = 0; d < 3; d++) ok = ok && (s[d] == 0 || cut[d]);
+                    if (!ok) continue;
+                    int n[3];
+                    for (int d = 0; d < 3; d++) {
+                        const int c = coords[d] + s[d];
+                        dir[ndirs][d] = s[d];
+                        dir_shift[ndirs][d] = c >= grid[d] ? -L[d] : (c < 0 ? L[d] : 0.0);
+                        n[d] = ((c % grid[d]) + grid[d]) % grid[d];
+                    }
+                    dir_rank[ndirs] = n[0] + grid[0] * (n[1] + grid[1] * n[2]);
+                    ndirs++;
+                }
+        npeers = 0;
+        for (int r = 0; r < world; r++) {
+            if (r == rank) continue;
+            for (int k = 0; k < ndirs; k++)
+                if (dir_rank[k] == r) { peers[npeers++] = r; break; }
+        }
+        // a rank may be its own neighbour only along a dimension with one brick, and those are not cut
+        for (int k = 0; k < ndirs; k++) EMDEE_REQUIRE(dir_rank[k] != rank, EMDEE_ERR_INVALID, "emdee_dd: a brick neighbours itself");
+        ghost_nbins = 0;
+        for (int p = 0; p < npeers; p++) {
+            peer_bin_lo[p] = ghost_nbins;
+            for (int k = 0; k < ndirs; k++)
+                if (dir_rank[k] == peers[p]) { dir_of_bin[ghost_nbins] = k; bin_of_dir[k] = ghost_nbins; ghost_nbins++; }
+        }
+        peer_bin_lo[npeers] = ghost_nbins;
+        peer_bin_lo[npeers + 1] = ghost_nbins;
+    }
+
+    template <typename real>
+    DdDev<real> device() const {
+        DdDev<real> g{};
+        for (int d = 0; d < 3; d++) {
+            g.L[d] = (real)L[d]; g.width[d] = (real)width[d]; g.lo[d] = (real)lo[d]; g.hi[d] = (real)hi[d];
+            g.grid[d] = grid[d]; g.cut[d] = cut[d];
+        }
+        g.halo = (real)halo; g.rank = rank; g.world = world; g.ndirs = ndirs;
+        for (int k = 0; k < ndirs; k++) {
+            for (int d = 0; d < 3; d++) { g.dir[k][d] = dir[k][d]; g.shift[k][d] = (real)dir_shift[k][d]; }
+            g.dir_bin[k] = bin_of_dir[k];
+            g.bin_dir[bin_of_dir[k]] = k;
+        }
+        for (int r = 0; r < DD_MAX_WORLD; r++) g.rank_bin[r] = -1;
+        g.rank_bin[rank] = 0;
+        for (int p = 0; p < npeers; p++) g.rank_bin[peers[p]] = 1 + p;
+        return g;
+    }
+};
+
+// what one domain hands to a transport call: one message per peer, both ways
+struct Xfer {
+    const unsigned char *send = nullptr;
+    unsigned char *recv = nullptr;
+    size_t soff[DD_MAX_PEERS], sbytes[DD_MAX_PEERS], roff[DD_MAX_PEERS], rbytes[DD_MAX_PEERS];
+};
+
+constexpr int DD_MAX_BATCH = 8;
+constexpr int DD_WORDS = 2 * (DD_MAX_BATCH + 2);   // V[0..MAXB+1] | G[0..MAXB+1]
+
+// ------------------------------------------------------------------------------------ one domain
+template <typename real>
+struct Domain {
+    DdGeom geo;
+    emdee_ctx *ctx = nullptr;            // compute stream (+ pinned words)
+    bool owns_ctx = false;
+    hipStream_t comm = nullptr;          // communication stream
+    hipEvent_t ev_packed = nullptr, ev_done = nullptr;
+    std::unique_ptr<MdImpl<real>> md;
+    // caller-order working arrays (owned first, then ghosts for x and atoms), double-buffered across a migration
+    DevBuf<real> x, x2, v, v2, f;
+    DevBuf<emdee_lj_atom> at, at2;
+    DevBuf<long long> gid, gid2;
+    DevBuf<unsigned> mask;
+    DevBuf<int> counts, ids, bins, codes, small;   // small: bin_start[33] | cnt_send[27] | cnt_recv[27] | err[1]
+    DevBuf<unsigned char> sendbuf, recvbuf;
+    DevBuf<int> words;
+    DevBuf<double> red;
+    Scanner scanner;
+    int n_owned = 0, n_ghost = 0, n_send = 0;
+    int host_small[96];
+    DdPlan plan{};
+    Xfer xf{};
+    int since_build = 0;
+
+    int *V(int j) { return words.ptr + j; }
+    int *G(int j) { return words.ptr + (DD_MAX_BATCH + 2) + j; }
+    hipStream_t stream() const { return ctx->stream; }
+    NbSystem<real> &sys() { return md->sys; }
+};
+
+// ------------------------------------------------------------------------------------ the decomposition
+template <typename real>
+struct DdImpl : IDd {
+    emdee_ctx *user_ctx;
+    double L[3], skin, halo;
+    int grid[3], world;
+    emdee_lj_model model;
+    std::vector<std::unique_ptr<Domain<real>>> dom;   // local domains, ranks rank_first .. rank_first + n_local - 1
+    int rank_first, n_local;
+    bool use_rccl = false;
+    RcclApi::Comm comm = nullptr;
+    bool loaded = false;
+    int64_t n_global = 0;
+    int max_batch = 4;
+    bool overlap = true;
+    int last_interval = 0;
+    // Langevin
+    bool lgv_on = false;
+    double lgv_gamma = 0, lgv_T = 0;
+    uint64_t lgv_seed = 0, lgv_first = 0;
+    int64_t stat_batches = 0, stat_cancelled = 0, stat_rebuilds = 0, stat_migrated = 0;
+
+    DdImpl(emdee_ctx *c, const double len[3], const int g[3], int rank_first_, int n_local_, const void *unique_id,
+           const emdee_lj_model &m, double skin_)
+        : user_ctx(c), skin(skin_), model(m), rank_first(rank_first_), n_local(n_local_) {
+        use_device(c);
+        for (int d = 0; d < 3; d++) {
+            L[d] = len[d]; grid[d] = g[d];
+            EMDEE_REQUIRE(g[d] >= 1 && len[d] > 0, EMDEE_ERR_INVALID, "emdee_dd: grid and box lengths must be positive");
+        }
+        world = g[0] * g[1] * g[2];
+        EMDEE_REQUIRE(world <= DD_MAX_WORLD, EMDEE_ERR_INVALID, "emdee_dd: at most %d domains", DD_MAX_WORLD);
+        EMDEE_REQUIRE(n_local >= 1 && rank_first >= 0 && rank_first + n_local <= world, EMDEE_ERR_INVALID,
+                      "emdee_dd: local ranks [%d, %d) outside the %d-domain grid", rank_first, rank_first + n_local, world);
+        EMDEE_REQUIRE(m.rc2 > 0 && skin >= 0, EMDEE_ERR_INVALID, "emdee_dd: bad model or skin");
+        halo = std::sqrt(m.rc2) + skin;
+        use_rccl = n_local < world;
+        if (use_rccl) {
+            EMDEE_REQUIRE(n_local == 1, EMDEE_ERR_INVALID, "emdee_dd: one domain per process when the domains span processes");
+            EMDEE_REQUIRE(unique_id != nullptr, EMDEE_ERR_INVALID, "emdee_dd: a communicator id (emdee_dd_unique_id) is needed");
+        }
+        if (const char *e = std::getenv("EMDEE_DD_BATCH")) max_batch = std::max(1, std::min(DD_MAX_BATCH, std::atoi(e)));
+        if (const char *e = std::getenv("EMDEE_DD_OVERLAP")) overlap = std::atoi(e) != 0;
+        for (int l = 0; l < n_local; l++) {
+            auto d = std::make_unique<Domain<real>>();
+            d->geo.init(L, grid, halo, rank_first + l);
+            if (use_rccl) {
+                d->ctx = c;
+            } else {
+                d->ctx = new emdee_ctx(*c);
+                d->owns_ctx = true;
+                EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->ctx->stream, hipStreamNonBlocking));
+                EMDEE_HIP_CHECK(hipHostMalloc((void **)&d->ctx->host_flags, 16 * sizeof(int32_t), hipHostMallocDefault));
+                memset(d->ctx->host_flags, 0, 16 * sizeof(int32_t));
+            }
+            EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+            EMDEE_HIP_CHECK(hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming));
+            EMDEE_HIP_CHECK(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
+            const int32_t per[3] = {d->geo.periodic[0], d->geo.periodic[1], d->geo.periodic[2]};
+            d->md = std::make_unique<MdImpl<real>>(d->ctx, d->geo.local_lo, d->geo.local_len, per, model, skin);
+            d->words.ensure(DD_WORDS);
+            d->small.ensure(96);
+            d->red.ensure(8);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d->words.ptr, 0, DD_WORDS * sizeof(int), d->stream()));
+            dom.push_back(std::move(d));
+        }
+        if (use_rccl) {
+            RcclApi &api = RcclApi::get();
+            api.load();
+            RcclApi::UniqueId id;
+            memcpy(&id, unique_id, sizeof(id));
+            EMDEE_RCCL_CHECK(api.CommInitRank(&comm, world, id, rank_first));
+        }
+    }
+
+    ~DdImpl() override {
+        (void)hipSetDevice(user_ctx->device);
+        for (auto &d : dom) {
+            (void)hipStreamSynchronize(d->stream());
+            (void)hipStreamSynchronize(d->comm);
+        }
+        if (comm) (void)RcclApi::get().CommDestroy(comm);
+        for (auto &d : dom) {
+            d->md.reset();
+            (void)hipEventDestroy(d->ev_packed);
+            (void)hipEventDestroy(d->ev_done);
+            (void)hipStreamDestroy(d->comm);
+            if (d->owns_ctx) {
+                (void)hipStreamDestroy(d->ctx->stream);
+                (void)hipHostFree(d->ctx->host_flags);
+                delete d->ctx;
+            }
+        }
+    }
+
+    Domain<real> &local(int l) {
+        EMDEE_REQUIRE(l >= 0 && l < n_local, EMDEE_ERR_INVALID, "emdee_dd: local domain %d out of range [0, %d)", l, n_local);
+        return *dom[l];
+    }
+    void sync_all() {
+        for (auto &d : dom) {
+            EMDEE_HIP_CHECK(hipStreamSynchronize(d->comm));
+            EMDEE_HIP_CHECK(hipStreamSynchronize(d->stream()));
+        }
+    }
+
+    // ---------------------------------------------------------------- transports
+    // Every local domain has filled its Xfer and recorded ev_packed on its compute stream once the send buffer is
+    // complete.  Afterwards ev_done (communication stream) marks the arrival of all its messages.
+    void exchange() {
+        if (use_rccl) {
+            RcclApi &api = RcclApi::get();
+            Domain<real> &d = *dom[0];
+            EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, d.ev_packed, 0));
+            if (d.geo.npeers > 0) {
+                EMDEE_RCCL_CHECK(api.GroupStart());
+                for (int p = 0; p < d.geo.npeers; p++) {
+                    if (d.xf.sbytes[p]) EMDEE_RCCL_CHECK(api.Send(d.xf.send + d.xf.soff[p], d.xf.sbytes[p], RcclApi::kChar, d.geo.peers[p], comm, d.comm));
+                    if (d.xf.rbytes[p]) EMDEE_RCCL_CHECK(api.Recv(d.xf.recv + d.xf.roff[p], d.xf.rbytes[p], RcclApi::kChar, d.geo.peers[p], comm, d.comm));
+                }
+                EMDEE_RCCL_CHECK(api.GroupEnd());
+            }
+            EMDEE_HIP_CHECK(hipEventRecord(d.ev_done, d.comm));
+            return;
+        }
+        // all domains in this process: the receiver's communication stream copies from the sender's buffer
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, d.ev_packed, 0));   // (my receive buffer has been consumed)
+            for (int p = 0; p < d.geo.npeers; p++) {
+                Domain<real> &s = *dom[d.geo.peers[p] - rank_first];
+                const int q = s.geo.peer_index(d.geo.rank);
+                EMDEE_REQUIRE(q >= 0 && s.xf.sbytes[q] == d.xf.rbytes[p], EMDEE_ERR_STATE,
+                              "emdee_dd: message sizes of domains %d and %d disagree (%zu sent, %zu expected)", s.geo.rank,
+                              d.geo.rank, q >= 0 ? s.xf.sbytes[q] : (size_t)0, d.xf.rbytes[p]);
+                EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, s.ev_packed, 0));
+                if (d.xf.rbytes[p])
+                    EMDEE_HIP_CHECK(hipMemcpyAsync(d.xf.recv + d.xf.roff[p], s.xf.send + s.xf.soff[q], d.xf.rbytes[p],
+                                                   hipMemcpyDeviceToDevice, d.comm));
+            }
+        }
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipEventRecord(pd->ev_done, pd->comm));
+    }
+    // compute streams wait for the arrival of their messages -- and, with in-process copies, for everybody
+    // who reads this domain's send buffer, before it is packed again
+    void wait_exchange() {
+        for (auto &pd : dom) {
+            EMDEE_HIP_CHECK(hipStreamWaitEvent(pd->stream(), pd->ev_done, 0));
+            if (!use_rccl)
+                for (int p = 0; p < pd->geo.npeers; p++)
+                    EMDEE_HIP_CHECK(hipStreamWaitEvent(pd->stream(), dom[pd->geo.peers[p] - rank_first]->ev_done, 0));
+        }
+    }
+    // sum of n doubles over all domains (vals: per local domain n values on the host; result in out)
+    void allreduce_sum(const std::vector<std::vector<double>> &vals, int n, double *out) {
+        for (int k = 0; k < n; k++) out[k] = 0.0;
+        for (auto &v : vals)
+            for (int k = 0; k < n; k++) out[k] += v[k];
+        if (!use_rccl) return;
+        Domain<real> &d = *dom[0];
+        EMDEE_REQUIRE(n <= 8, EMDEE_ERR_INVALID, "allreduce_sum: at most 8 values");
+        EMDEE_HIP_CHECK(hipMemcpyAsync(d.red.ptr, out, n * sizeof(double), hipMemcpyHostToDevice, d.stream()));
+        EMDEE_RCCL_CHECK(RcclApi::get().AllReduce(d.red.ptr, d.red.ptr, (size_t)n, RcclApi::kFloat64, RcclApi::kSum, comm, d.stream()));
+        EMDEE_HIP_CHECK(hipMemcpyAsync(out, d.red.ptr, n * sizeof(double), hipMemcpyDeviceToHost, d.stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(d.stream()));
+    }
+
+    // ---------------------------------------------------------------- state in
+    void set_atoms(int l, int n, const void *pos, const void *vel, const emdee_lj_atom *atoms, const int64_t *gids) override {
+        use_device(user_ctx);
+        Domain<real> &d = local(l);
+        EMDEE_REQUIRE(n >= 0 && (n == 0 || (pos && vel && atoms && gids)), EMDEE_ERR_INVALID, "emdee_dd_set_atoms: NULL array");
+        d.x.ensure(3 * (size_t)n + 3); d.v.ensure(3 * (size_t)n + 3); d.at.ensure((size_t)n + 1); d.gid.ensure((size_t)n + 1);
+        hipStream_t s = user_ctx->stream;
+        if (n > 0) {
+            EMDEE_HIP_CHECK(hipMemcpyAsync(d.x.ptr, pos, 3 * (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
+            EMDEE_HIP_CHECK(hipMemcpyAsync(d.v.ptr, vel, 3 * (size_t)n * sizeof(real), hipMemcpyDeviceToDevice, s));
+            EMDEE_HIP_CHECK(hipMemcpyAsync(d.at.ptr, atoms, (size_t)n * sizeof(emdee_lj_atom), hipMemcpyDeviceToDevice, s));
+            EMDEE_HIP_CHECK(hipMemcpyAsync(d.gid.ptr, gids, (size_t)n * sizeof(long long), hipMemcpyDeviceToDevice, s));
+        }
+        EMDEE_HIP_CHECK(hipStreamSynchronize(s));
+        d.n_owned = n;
+        d.n_ghost = 0;
+        loaded = false;
+    }
+
+    // collective: hand every atom to the brick that contains it, choose and exchange the ghosts, load the engines
+    void load() override {
+        use_device(user_ctx);
+        redistribute(false);
+        if (n_global == 0) {
+            std::vector<std::vector<double>> v;
+            for (auto &d : dom) v.push_back({(double)d->n_owned});
+            double tot = 0;
+            allreduce_sum(v, 1, &tot);
+            n_global = (int64_t)(tot + 0.5);
+        }
+        loaded = true;
+    }
+
+    // stable partition of items 0..n-1 by mask bits into nbins bins: counts and scanned offsets (device), starts and
+    // per-peer counts into small[0..] / small[33..]
+    void partition_count(Domain<real> &d, int n, int nbins, const DdBins &pb) {
+        const int nblocks = std::max(1, (int)blocks_for(n, PART_BLOCK));
+        d.counts.ensure((size_t)nbins * nblocks + 2);
+        EMDEE_HIP_CHECK(hipMemsetAsync(d.counts.ptr, 0, ((size_t)nbins * nblocks + 1) * sizeof(int), d.stream()));
+        if (n > 0)
+            hipLaunchKernelGGL(k_part_count, dim3(nblocks), dim3(PART_BLOCK), 0, d.stream(), n, d.mask.ptr, nbins, nblocks, d.counts.ptr);
+        d.scanner.run(d.counts.ptr, (size_t)nbins * nblocks + 1, d.stream());
+        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, d.stream(), nbins, nblocks, d.counts.ptr, d.small.ptr, pb, d.small.ptr + 33);
+    }
+    void partition_scatter(Domain<real> &d, int n, int nbins, int total, bool with_bins) {
+        const int nblocks = std::max(1, (int)blocks_for(n, PART_BLOCK));
+        d.ids.ensure((size_t)total + 1);
+        if (with_bins) d.bins.ensure((size_t)total + 1);
+        if (n > 0)
+            hipLaunchKernelGGL(k_part_scatter, dim3(nblocks), dim3(PART_BLOCK), 0, d.stream(), n, d.mask.ptr, nbins, nblocks,
+                               d.counts.ptr, d.ids.ptr, with_bins ? d.bins.ptr : nullptr);
+    }
+    // exchange the per-peer counts in small[33..33+npeers) -> small[60..60+npeers), then read small back (blocking)
+    void exchange_counts_and_read() {
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            d.xf.send = reinterpret_cast<const unsigned char *>(d.small.ptr + 33);
+            d.xf.recv = reinterpret_cast<unsigned char *>(d.small.ptr + 60);
+            for (int p = 0; p < d.geo.npeers; p++) {
+                d.xf.soff[p] = d.xf.roff[p] = (size_t)p * sizeof(int);
+                d.xf.sbytes[p] = d.xf.rbytes[p] = sizeof(int);
+            }
+            EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
+        }
+        exchange();
+        wait_exchange();
+        for (auto &pd : dom)
+            EMDEE_HIP_CHECK(hipMemcpyAsync(pd->host_small, pd->small.ptr, 96 * sizeof(int), hipMemcpyDeviceToHost, pd->stream()));
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
+    }
+    // variable-size rows: send counts small[33+p], receive counts small[60+p] (host copies), row_bytes each
+    void exchange_rows(size_t row_bytes) {
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            size_t so = 0, ro = 0;
+            for (int p = 0; p < d.geo.npeers; p++) {
+                d.xf.soff[p] = so; d.xf.sbytes[p] = (size_t)d.host_small[33 + p] * row_bytes; so += d.xf.sbytes[p];
+                d.xf.roff[p] = ro; d.xf.rbytes[p] = (size_t)d.host_small[60 + p] * row_bytes; ro += d.xf.rbytes[p];
+            }
+            d.xf.send = d.sendbuf.ptr;
+            d.xf.recv = d.recvbuf.ptr;
+            EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
+        }
+        exchange();
+        wait_exchange();
+    }
+
+    void redistribute(bool from_engines) {
+        // ---- 0. caller-order copies of the integrated state
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            if (from_engines) {
+                d.x.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3);   // (never grows here: sized at the previous load)
+                d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr);
+            }
+            d.mask.ensure((size_t)d.n_owned + 1);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
+            // ---- 1. owner of every atom; partition into stay | one bin per peer
+            if (d.n_owned > 0)
+                hipLaunchKernelGGL((k_dd_classify<real>), dim3(blocks_for(d.n_owned, 256)), dim3(256), 0, d.stream(), d.n_owned,
+                                   d.x.ptr, d.geo.template device<real>(), d.mask.ptr, d.small.ptr + 95);
+            DdBins pb{};
+            pb.npeers = d.geo.npeers;
+            for (int p = 0; p <= d.geo.npeers + 1; p++) pb.lo[p] = std::min(1 + p, 1 + d.geo.npeers);
+            partition_count(d, d.n_owned, 1 + d.geo.npeers, pb);
+        }
+        exchange_counts_and_read();
+        // ---- 2. move the leavers
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            EMDEE_REQUIRE(d.host_small[95] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom of domain %d left the neighbourhood of its brick", d.geo.rank);
+            const int nb = 1 + d.geo.npeers, total = d.host_small[nb], n_stay = d.host_small[1];
+            partition_scatter(d, d.n_owned, nb, total, false);
+            const int n_leave = total - n_stay;
+            int n_arrive = 0;
+            for (int p = 0; p < d.geo.npeers; p++) n_arrive += d.host_small[60 + p];
+            d.sendbuf.ensure((size_t)n_leave * sizeof(MigRow<real>) + 64);
+            d.recvbuf.ensure((size_t)n_arrive * sizeof(MigRow<real>) + 64);
+            if (n_leave > 0)
+                hipLaunchKernelGGL((k_dd_pack_migrants<real>), dim3(blocks_for(n_leave, 256)), dim3(256), 0, d.stream(), n_stay, total,
+                                   d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, reinterpret_cast<MigRow<real> *>(d.sendbuf.ptr));
+            stat_migrated += n_leave;
+        }
+        exchange_rows(sizeof(MigRow<real>));
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int n_stay = d.host_small[1];
+            int n_arrive = 0;
+            for (int p = 0; p < d.geo.npeers; p++) n_arrive += d.host_small[60 + p];
+            const int n_new = n_stay + n_arrive;
+            // (ghost capacity is added below, once the ghost count is known; x2 holds the owned part for now)
+            d.x2.ensure(3 * (size_t)n_new + 3); d.v2.ensure(3 * (size_t)n_new + 3); d.at2.ensure((size_t)n_new + 1); d.gid2.ensure((size_t)n_new + 1);
+            if (n_new > 0)
+                hipLaunchKernelGGL((k_dd_assemble_owned<real>), dim3(blocks_for(n_new, 256)), dim3(256), 0, d.stream(), n_stay, n_arrive,
+                                   d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, reinterpret_cast<const MigRow<real> *>(d.recvbuf.ptr),
+                                   d.x2.ptr, d.v2.ptr, d.at2.ptr, d.gid2.ptr);
+            d.x.swap(d.x2); d.v.swap(d.v2); d.at.swap(d.at2); d.gid.swap(d.gid2);
+            d.n_owned = n_new;
+            // ---- 3. ghosts: which neighbours need which of my atoms
+            d.mask.ensure((size_t)n_new + 1);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
+            if (n_new > 0 && d.geo.ghost_nbins > 0)
+                hipLaunchKernelGGL((k_dd_ghost_mask<real>), dim3(blocks_for(n_new, 256)), dim3(256), 0, d.stream(), n_new, d.x.ptr,
+                                   d.geo.template device<real>(), d.mask.ptr);
+            DdBins pb{};
+            pb.npeers = d.geo.npeers;
+            for (int p = 0; p <= d.geo.npeers + 1; p++) pb.lo[p] = d.geo.peer_bin_lo[std::min(p, d.geo.npeers)];
+            partition_count(d, d.geo.ghost_nbins > 0 ? n_new : 0, std::max(1, d.geo.ghost_nbins), pb);
+        }
+        exchange_counts_and_read();
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int nb = std::max(1, d.geo.ghost_nbins), total = d.geo.ghost_nbins > 0 ? d.host_small[nb] : 0;
+            partition_scatter(d, d.geo.ghost_nbins > 0 ? d.n_owned : 0, nb, total, true);
+            d.n_send = total;
+            d.n_ghost = 0;
+            d.plan = DdPlan{};
+            d.plan.npeers = d.geo.npeers;
+            for (int p = 0; p < d.geo.npeers; p++) {
+                d.plan.send_start[p + 1] = d.plan.send_start[p] + d.host_small[33 + p];
+                d.plan.recv_start[p + 1] = d.plan.recv_start[p] + d.host_small[60 + p];
+            }
+            d.n_ghost = d.plan.recv_start[d.geo.npeers];
+            EMDEE_REQUIRE(d.plan.send_start[d.geo.npeers] == total, EMDEE_ERR_STATE, "emdee_dd: ghost send list inconsistent");
+            d.codes.ensure((size_t)total + 1);
+            d.sendbuf.ensure((size_t)total * sizeof(GhostRow<real>) + 64);
+            d.recvbuf.ensure((size_t)d.n_ghost * sizeof(GhostRow<real>) + 64);
+            // room for the ghosts behind the owned atoms (contents preserved by hand: DevBuf::ensure does not)
+            grow_keep(d.x, 3 * (size_t)d.n_owned, 3 * (size_t)(d.n_owned + d.n_ghost) + 3, d.stream());
+            grow_keep(d.at, (size_t)d.n_owned, (size_t)(d.n_owned + d.n_ghost) + 1, d.stream());
+            if (total > 0)
+                hipLaunchKernelGGL((k_dd_pack_ghost_rows<real>), dim3(blocks_for(total, 256)), dim3(256), 0, d.stream(), total,
+                                   d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), d.x.ptr, d.at.ptr,
+                                   reinterpret_cast<GhostRow<real> *>(d.sendbuf.ptr), d.codes.ptr);
+        }
+        exchange_rows(sizeof(GhostRow<real>));
+        // ---- 4. load the engines: bin, sort, neighbour list, forces
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            if (d.n_ghost > 0)
+                hipLaunchKernelGGL((k_dd_unpack_ghost_rows<real>), dim3(blocks_for(d.n_ghost, 256)), dim3(256), 0, d.stream(), d.n_ghost,
+                                   reinterpret_cast<const GhostRow<real> *>(d.recvbuf.ptr), d.x.ptr + 3 * (size_t)d.n_owned,
+                                   d.at.ptr + d.n_owned);
+            d.md->set_state(d.n_owned, d.n_ghost, d.x.ptr, d.v.ptr, d.at.ptr, nullptr);
+            if (lgv_on) d.md->set_langevin_ids(reinterpret_cast<const int64_t *>(d.gid.ptr));
+            d.since_build = 0;
+            // per-step messages: header + 3 reals per atom and peer
+            const size_t w = sizeof(real);
+            const int np = d.geo.npeers;
+            d.sendbuf.ensure(dd_msg_begin(d.plan.send_start, np, w) + 64);
+            d.recvbuf.ensure(dd_msg_begin(d.plan.recv_start, np, w) + 64);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+        }
+        stat_rebuilds++;
+    }
+
+    static void grow_keep(DevBuf<real> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
+    static void grow_keep(DevBuf<emdee_lj_atom> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
+    template <typename T>
+    static void grow_keep_t(DevBuf<T> &b, size_t keep, size_t want, hipStream_t s) {
+        if (want <= b.cap) return;
+        DevBuf<T> nb;
+        nb.ensure(want);
+        if (keep) EMDEE_HIP_CHECK(hipMemcpyAsync(nb.ptr, b.ptr, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(s));
+        b.swap(nb);
+    }
+
+    // ---------------------------------------------------------------- one halo exchange around a compute call
+    // pack (request word = *V) -> exchange || compute(1) -> unpack (G |= requests) -> compute(2)
+    template <class F>
+    void with_halo(int vj, int gj, F &&compute) {
+        const size_t w = sizeof(real);
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int np = d.geo.npeers;
+            const int nthreads = std::max(d.n_send, std::max(np, 1));
+            hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_send, d.plan,
+                               d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr, d.V(vj),
+                               d.sendbuf.ptr);
+            for (int p = 0; p < np; p++) {
+                d.xf.soff[p] = dd_msg_begin(d.plan.send_start, p, w); d.xf.sbytes[p] = dd_msg_bytes(d.plan.send_start, p, w);
+                d.xf.roff[p] = dd_msg_begin(d.plan.recv_start, p, w); d.xf.rbytes[p] = dd_msg_bytes(d.plan.recv_start, p, w);
+            }
+            d.xf.send = d.sendbuf.ptr;
+            d.xf.recv = d.recvbuf.ptr;
+            EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
+        }
+        exchange();
+        if (overlap)
+            for (auto &pd : dom) compute(*pd, 1);
+        wait_exchange();
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int nthreads = std::max(d.n_ghost, std::max(d.geo.npeers, 1));
+            hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_ghost, d.n_owned,
+                               d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
+            d.md->current_mask = 0;
+            compute(d, overlap ? 2 : 0);
+        }
+    }
+
+    // ---------------------------------------------------------------- stepping
+    void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) override {
+        lgv_on = gamma > 0.0;
+        lgv_gamma = gamma; lgv_T = temperature; lgv_seed = seed; lgv_first = first_step;
+        for (auto &d : dom) {
+            d->md->set_langevin(gamma, temperature, seed, first_step);
+            d->md->set_langevin_ids(lgv_on && loaded ? reinterpret_cast<const int64_t *>(d->gid.ptr) : nullptr);
+        }
+    }
+
+    bool read_global_words(int first, int count, int *out) {
+        // identical on every domain by construction: read the first local one (debug builds could compare)
+        Domain<real> &d = *dom[0];
+        EMDEE_HIP_CHECK(hipMemcpyAsync(d.ctx->host_flags, d.G(first), count * sizeof(int), hipMemcpyDeviceToHost, d.stream()));
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
+        bool any = false;
+        for (int k = 0; k < count; k++) { out[k] = d.ctx->host_flags[k]; any = any || out[k] != 0; }
+        return any;
+    }
+
+    // plain force pass (all outputs in `bitmask`) at the current positions with fresh ghosts; true if the list was stale
+    // for them (then a rebuild has been done and the forces recomputed)
+    void forces_with_halo(int bitmask, int carry) {
+        for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
+        with_halo(0, 0, [&](Domain<real> &d, int phase) { d.md->forces(bitmask, phase); });
+        int g = 0;
+        if (read_global_words(0, 1, &g)) {
+            redistribute(true);
+            if (bitmask != EMDEE_FORCES)
+                for (auto &pd : dom) pd->md->forces(bitmask, 0);
+        }
+    }
+
+    void step(int nsteps, double dt, int rebuild_every) override {
+        use_device(user_ctx);
+        EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_step: call emdee_dd_load first");
+        EMDEE_REQUIRE(nsteps >= 0 && dt >= 0 && rebuild_every >= 0, EMDEE_ERR_INVALID, "emdee_dd_step: negative argument");
+        if (nsteps == 0) return;
+        const bool tiled = dom[0]->sys().brick_active;    // (the same kernels on every domain: same box class)
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            if (!(d.md->current_mask & EMDEE_FORCES)) EMDEE_REQUIRE(false, EMDEE_ERR_STATE, "emdee_dd_step: forces are not current");
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            d.sys().kick_drift(0.5 * dt, dt, d.V(0));       // x_1 = x_0 + dt (v_0 + dt/2 f_0)
+            d.md->current_mask = 0;
+        }
+        int s = 1, carry = 0;                               // carry: index of the word that flags the current positions
+        while (s < nsteps) {
+            // ---- a batch of inner steps: force + full kick + drift in one kernel pass each
+            int B = std::min(max_batch, nsteps - s);
+            if (rebuild_every > 0) B = std::min(B, std::max(1, rebuild_every - dom[0]->since_build - 1));
+            if (!tiled) B = 1;
+            if (rebuild_every > 0 && dom[0]->since_build + 1 >= rebuild_every) {
+                // fixed cadence: rebuild at the current positions, then the un-fused equivalent of one inner step
+                redistribute(true);
+                for (auto &pd : dom) {
+                    EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
+                    pd->sys().kick_drift(dt, dt, pd->V(0));
+                    pd->md->current_mask = 0;
+                    pd->since_build = 0;
+                }
+                carry = 0;
+                s++;
+                continue;
+            }
+            for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
+            for (int j = 0; j < B; j++) {
+                if (tiled) {
+                    with_halo(j, j, [&](Domain<real> &d, int phase) {
+                        // interior bricks look at my own request only (their neighbours are all mine); boundary bricks
+                        // at the OR of everybody's
+                        const int *guard = (phase == 1) ? d.V(j) : d.G(j);
+                        d.sys().fused_step(dt, dt, phase, rebuild_every > 0 ? nullptr : guard, d.V(j + 1), false);
+                    });
+                } else {
+                    // direct kernels (no guard words): decide on the host before the force pass
+                    with_halo(j, j, [&](Domain<real> &, int) {});
+                }
+            }
+            int g[DD_MAX_BATCH];
+            int ran = B;
+            stat_batches++;
+            if (rebuild_every == 0 && read_global_words(0, B, g)) {
+                for (int j = 0; j < B; j++)
+                    if (g[j]) { ran = j; break; }
+                stat_cancelled += B - ran;
+            }
+            if (!tiled && ran == 1) {
+                for (auto &pd : dom) {
+                    pd->md->forces(EMDEE_FORCES, 0);
+                    pd->sys().kick_drift(dt, dt, pd->V(1));
+                }
+            }
+            for (auto &pd : dom) {
+                Domain<real> &d = *pd;
+                if (tiled && ((B - ran) & 1)) d.sys().swap_step_buffers();   // the cancelled launches did not advance the ping-pong
+                if (tiled && d.sys().lgv_on) d.sys().lgv_step -= (unsigned long long)(B - ran);
+                if (tiled && d.sys().profiling) d.sys().timers[T_STEP].dropped += (overlap ? 2 : 1) * (B - ran);
+                d.since_build += ran;
+                d.md->current_mask = 0;
+            }
+            s += ran;
+            carry = ran;                                     // V[ran]: raised by step ran - 1 for the positions it produced
+            if (ran < B) {
+                // the positions of step s were flagged: rebuild there (evaluates the forces), then the un-fused
+                // equivalent of that inner step
+                redistribute(true);
+                last_interval = 0;
+                if (s < nsteps) {
+                    for (auto &pd : dom) {
+                        EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
+                        pd->sys().kick_drift(dt, dt, pd->V(0));
+                        pd->md->current_mask = 0;
+                    }
+                    carry = 0;
+                    s++;
+                }
+            }
+        }
+        // ---- last step: plain force pass and the closing half kick
+        if (dom[0]->md->current_mask & EMDEE_FORCES) {
+            // (a rebuild at the last positions has just evaluated them)
+        } else if (rebuild_every > 0 && dom[0]->since_build + 1 >= rebuild_every) {
+            redistribute(true);
+        } else {
+            forces_with_halo(EMDEE_FORCES, carry);
+        }
+        for (auto &pd : dom) {
+            pd->sys().kick(0.5 * dt);
+            pd->md->current_mask = EMDEE_FORCES;
+            EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
+        }
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
+
+    // ---------------------------------------------------------------- state out
+    void energies(double out[3]) override {
+        use_device(user_ctx);
+        EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_energies: call emdee_dd_load first");
+        std::vector<std::vector<double>> vals;
+        for (auto &pd : dom) {
+            // ghosts are current whenever the forces are (every force pass follows a halo unpack or a rebuild)
+            double e[3];
+            pd->md->energies(e);
+            vals.push_back({e[0], e[1], e[2]});
+        }
+        allreduce_sum(vals, 3, out);
+    }
+    int64_t n_atoms_global() override { return n_global; }
+    int n_owned(int l) override { return local(l).n_owned; }
+    int n_ghost(int l) override { return local(l).n_ghost; }
+    IMd *engine(int l) override { return local(l).md.get(); }
+    void get_state(int l, int64_t *gids, void *pos, void *vel, void *frc) override {
+        use_device(user_ctx);
+        Domain<real> &d = local(l);
+        EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_get_state: call emdee_dd_load first");
+        const size_t n = (size_t)d.n_owned;
+        d.f.ensure(3 * n + 3);
+        // caller-order copies of the whole domain (positions include the ghosts) into scratch, owned part out
+        d.x2.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3); d.v2.ensure(3 * n + 3);
+        d.sys().unsort(d.x2.ptr, d.v2.ptr, d.f.ptr, nullptr, nullptr);
+        hipStream_t s = d.stream();
+        if (n > 0) {
+            if (pos) EMDEE_HIP_CHECK(hipMemcpyAsync(pos, d.x2.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
+            if (vel) EMDEE_HIP_CHECK(hipMemcpyAsync(vel, d.v2.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
+            if (frc) EMDEE_HIP_CHECK(hipMemcpyAsync(frc, d.f.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
+            if (gids) EMDEE_HIP_CHECK(hipMemcpyAsync(gids, d.gid.ptr, n * sizeof(long long), hipMemcpyDeviceToDevice, s));
+        }
+        EMDEE_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    void stats(int64_t out[4]) override {
+        out[0] = stat_rebuilds; out[1] = stat_batches; out[2] = stat_cancelled; out[3] = stat_migrated;
+    }
+};
+
+template <typename real>
+IDd *Factory<real>::dd(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int rank_first, int n_local,
+                       const void *unique_id, const emdee_lj_model &model, double skin) {
+    const int g[3] = {grid[0], grid[1], grid[2]};
+    return new DdImpl<real>(ctx, len, g, rank_first, n_local, unique_id, model, skin);
+}
+
+}  // namespace emdee

@@ -47,8 +47,26 @@ struct IMd {
     virtual void langevin_normals(uint64_t seed, uint64_t step, const int64_t *ids, int n, double *out) = 0;
 };
 
+// spatial domain decomposition (emdee_dd_*): the domains of the decomposition that live in this process
+struct IDd {
+    virtual ~IDd() {}
+    virtual void set_atoms(int local, int n, const void *pos, const void *vel, const emdee_lj_atom *atoms, const int64_t *gids) = 0;
+    virtual void load() = 0;
+    virtual void step(int nsteps, double dt, int rebuild_every) = 0;
+    virtual void energies(double out[3]) = 0;
+    virtual int64_t n_atoms_global() = 0;
+    virtual int n_owned(int local) = 0;
+    virtual int n_ghost(int local) = 0;
+    virtual IMd *engine(int local) = 0;
+    virtual void get_state(int local, int64_t *gids, void *pos, void *vel, void *frc) = 0;
+    virtual void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) = 0;
+    virtual void stats(int64_t out[4]) = 0;
+};
+
 template <typename real>
 struct Factory {
+    static IDd *dd(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int rank_first, int n_local,
+                   const void *unique_id, const emdee_lj_model &model, double skin);
     static ICells *cells(emdee_ctx *ctx, int N, double L, double cutoff, int ndiv);
     static INbr *nbr(emdee_ctx *ctx, int N, double skin);
     static IMd *md(emdee_ctx *ctx, const double lo[3], const double len[3], const int32_t per[3],

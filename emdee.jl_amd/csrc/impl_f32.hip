@@ -1,6 +1,6 @@
 // impl_f32.hip -- fp32 instantiation (the reference's Float32; BASELINE config 4 mixed precision:
 // fp32 storage and pair math, fp64 global energy/virial reduction).
-#include "impl.hpp"
+#include "dd.hpp"
 
 namespace emdee {
 template struct Factory<float>;

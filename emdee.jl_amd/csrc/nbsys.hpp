@@ -256,6 +256,11 @@ struct NbSystem {
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
                                cell_sorted.ptr, img.ptr);
+        // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
+        // from the start; their coordinates are refreshed by every halo unpack
+        if (n > n_owned)
+            hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned,
+                               perm.ptr, rec.ptr, rec2.ptr);
         sorted = true;
         build_list();
     }
@@ -290,7 +295,7 @@ struct NbSystem {
         if (const char *dbg = std::getenv("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
-        a.vel = vel.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
+        a.vel = vel.ptr; a.vel_next = vel2.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
         a.kick_c = (real)step_c; a.dt = (real)step_dt;
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.thr2 = (real)(0.25 * skin * skin);
@@ -543,25 +548,34 @@ struct NbSystem {
 
     // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
     // the other position buffer.  False if the brick kernels are not in use (caller runs the split kernels).
-    bool fused_step(double c, double dt, int phase = 0) {
+    // guard / trigger (device words, optional): the launch does nothing but raise *trigger when *guard is set, and
+    // raises *trigger when an atom it moved is now skin/2 away from its position at the last build (default: flags[1]).
+    // carry_ghosts: copy the ghosts' current coordinates into the buffer that becomes current (callers that unpack
+    // fresh ghosts before every force evaluation, as emdee_dd_step does, do not need it).
+    bool fused_step(double c, double dt, int phase = 0, const int *guard = nullptr, int *trigger = nullptr,
+                    bool carry_ghosts = true) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         if (!brick_active || n_total == 0) return false;
         if (phase != 2) prepare_noise(dt);                   // phases 1 and 2 are the two halves of one step
-        Timed t(this, T_STEP);
-        step_c = c; step_dt = dt;
-        force_phase = phase;
-        with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
+        {
+            Timed t(this, T_STEP);
+            step_c = c; step_dt = dt;
+            force_phase = phase;
+            step_guard = guard; step_trigger = trigger;
+            with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
+            step_guard = nullptr; step_trigger = nullptr;
+        }
         if (phase != 1 && lgv_on) lgv_step++;
-        // Ghost records are never written by the step kernel: carry their current image over so that the
-        // buffer that becomes current next is complete even before the next halo unpack.
         if (phase != 1) {
-            if (n_total > n_owned)
+            if (carry_ghosts && n_total > n_owned)
                 hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(),
                                    n_total, n_owned, perm.ptr, rec.ptr, rec2.ptr);
-            rec.swap(rec2);
+            swap_step_buffers();
         }
         return true;
     }
+    // positions and velocities ping-pong together
+    void swap_step_buffers() { rec.swap(rec2); vel.swap(vel2); }
 
     // Up to RUN_AHEAD fused steps queued back to back, with ONE read-back for the whole batch instead of a
     // host round trip per step: launch i raises word i when an atom has moved skin/2, launch i + 1 looks at
@@ -586,7 +600,7 @@ struct NbSystem {
             step_trigger = words + i;
             step_guard = i ? words + i - 1 : nullptr;
             with_brick_variant(variant, [&](auto v) { launch_brick_kernel<decltype(v), BRICK_STEP, 1>(); });
-            rec.swap(rec2);
+            swap_step_buffers();
         }
         step_trigger = nullptr; step_guard = nullptr;
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 9, words, B * sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -594,7 +608,7 @@ struct NbSystem {
         int ran = B;
         for (int i = 0; i < B; i++)
             if (ctx->host_flags[9 + i]) { ran = i + 1; *stale = true; break; }
-        if ((B - ran) & 1) rec.swap(rec2);                   // the skipped launches did not advance the ping-pong
+        if ((B - ran) & 1) swap_step_buffers();              // the skipped launches did not advance the ping-pong
         if (lgv_on) lgv_step -= (unsigned long long)(B - ran);
         if (profiling) timers[T_STEP].dropped += B - ran;
         return ran;
@@ -626,7 +640,7 @@ struct NbSystem {
     }
 
     // ---------------------------------------------------------------- integrator
-    void kick_drift(double c, double dt) {
+    void kick_drift(double c, double dt, int *trigger = nullptr) {
         EMDEE_REQUIRE(sorted && with_vel, EMDEE_ERR_STATE, "no velocities loaded");
         if (n_total == 0) return;
         prepare_noise(dt);
@@ -634,7 +648,7 @@ struct NbSystem {
         real thr = (real)(0.5 * skin);
         hipLaunchKernelGGL((k_kick_drift<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
                            pitch, perm.ptr, rec.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c, (real)dt,
-                           xb.ptr, thr * thr, flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1);
+                           xb.ptr, thr * thr, trigger ? trigger : flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1);
         if (lgv_on) lgv_step++;
     }
 

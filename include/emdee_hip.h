@@ -75,6 +75,7 @@ typedef struct emdee_ctx   emdee_ctx;     /* device + stream                    
 typedef struct emdee_cells emdee_cells;   /* Cells                                (src/cells.jl:6-20) */
 typedef struct emdee_nbr   emdee_nbr;     /* neighbour handle carried by `tiles`  (src/nonbonded.jl:18-26) */
 typedef struct emdee_md    emdee_md;      /* velocity-Verlet state                (absent from the reference) */
+typedef struct emdee_dd    emdee_dd;      /* spatial domain decomposition         (absent from the reference) */
 
 /* ---------------------------------------------------------------- context */
 const char *emdee_last_error(void);
@@ -243,6 +244,49 @@ int32_t emdee_md_set_langevin_ids(emdee_md *md, const int64_t *ids_dev);
 /* The generator on its own, for tests: out_dev[3 i .. 3 i + 2] = xi(seed, step, ids_dev[i]). */
 int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, const int64_t *ids_dev, int32_t n,
                                   double *out_dev);
+
+/* ---------------------------------------------------------------- domain decomposition (multi-GPU)
+ * Build-defined (the reference is single-GPU; SURVEY.md 8(b) table rows emdee_dd_create / emdee_dd_step, 8(e)).
+ * The periodic box [0, len_d) is cut into grid[0] x grid[1] x grid[2] bricks (at most 3 per dimension), domain
+ * rank = cx + grid[0] (cy + grid[1] cz).  One emdee_dd drives the domains rank_first .. rank_first + n_local - 1:
+ *   - one process per GPU: n_local = 1 and unique_id = the 128 bytes of emdee_dd_unique_id() as generated by ONE
+ *     process and distributed by the caller (Julia Distributed / MPI / torch.distributed); the halo messages then
+ *     travel over RCCL (ncclSend/ncclRecv over xGMI), resolved from librccl.so.1 at run time;
+ *   - n_local = the whole grid, unique_id = NULL: every domain in this process on the context's device, messages
+ *     as device-to-device copies (validation of a decomposition on a one-GPU box).
+ * A step is, per domain, pack -> halo exchange on a communication stream || force + kick + drift of the interior
+ * bricks -> unpack -> the boundary bricks; the steps of a call are queued a few at a time with device-side guard
+ * words (the rebuild request rides on the halo messages), one host read-back per batch.  Rebuild = migration of
+ * the atoms that left their brick + new ghost lists + re-sort + neighbour list.  Trajectories are those of the
+ * undivided box to rounding. */
+int32_t emdee_dd_unique_id(uint8_t out[128]);
+int32_t emdee_dd_create(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int32_t rank_first, int32_t n_local,
+                        const uint8_t *unique_id, emdee_lj_model model, double skin, int32_t precision, emdee_dd **out);
+int32_t emdee_dd_destroy(emdee_dd *dd);
+/* Atoms initially held by local domain `local` (any atoms of the box, anywhere: emdee_dd_load hands each to the brick
+ * that contains it).  Device arrays in caller order: positions, velocities 3 x n reals; atoms n; gids n global ids
+ * (they key the Langevin noise and identify atoms in emdee_dd_get_state).  Copied. */
+int32_t emdee_dd_set_atoms(emdee_dd *dd, int32_t local, int32_t n, const void *positions_dev, const void *velocities_dev,
+                           const emdee_lj_atom *atoms_dev, const int64_t *gids_dev);
+/* Collective over all domains: migrate, select and exchange ghosts, bin/sort/list, forces. */
+int32_t emdee_dd_load(emdee_dd *dd);
+/* nsteps velocity-Verlet steps of the whole box (collective).  rebuild_every as in emdee_md_step. */
+int32_t emdee_dd_step(emdee_dd *dd, int32_t nsteps, double dt, int32_t rebuild_every);
+/* global {potential, kinetic, virial} sums (collective, blocking) */
+int32_t emdee_dd_energies(emdee_dd *dd, double out[3]);
+/* atoms in the whole box / owned and ghost atoms of a local domain */
+int32_t emdee_dd_counts(emdee_dd *dd, int32_t local, int64_t *n_global, int32_t *n_owned, int32_t *n_ghost);
+/* owned atoms of a local domain: global ids and positions (wrapped into the global box at the last rebuild),
+ * velocities, forces; n_owned entries each, any pointer may be NULL.  Blocking. */
+int32_t emdee_dd_get_state(emdee_dd *dd, int32_t local, int64_t *gids_dev, void *positions_dev, void *velocities_dev,
+                           void *forces_dev);
+/* the integrator of a local domain, for the emdee_md_* queries (profile, kernel_time, nbr_stats, count_pairs);
+ * borrowed: valid until emdee_dd_destroy, not to be stepped or destroyed by the caller */
+int32_t emdee_dd_engine(emdee_dd *dd, int32_t local, emdee_md **out);
+int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, uint64_t seed, uint64_t first_step);
+/* out[0] = rebuilds, out[1] = batches of queued steps, out[2] = queued steps cancelled by a rebuild request,
+ * out[3] = atoms that changed owner (this process) */
+int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,153 @@
+"""GPU tests of the decomposition behind the C ABI (emdee_dd_*): migration, ghost
+selection, per-step halo messages with the rebuild request riding on them, batches of queued steps with
+device-side guard words.  The one-GPU test box cannot host two RCCL ranks, so the whole decomposition runs
+in ONE process on cuda:0 (n_local = world: the transport is device-to-device copies between the domains'
+streams; everything else is the production path) and the trajectory must match the CPU oracle on the
+undivided periodic box."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+RC, RS, SKIN, DT = 2.5, 2.0, 0.3, 0.005
+NCELL = 8
+LANGEVIN = (2.0, 0.7, 0x5EED)
+
+
+def _global_box(syn, uniform=False, ncell=NCELL):
+    pos, gid, lengths = syn.fcc_block((ncell,) * 3, (0, 0, 0), (ncell,) * 3)
+    pos = pos[np.argsort(gid)]
+    N = pos.shape[0]
+    vel = syn.raw_normals(np.arange(N), N)
+    vel -= vel.mean(axis=0)
+    vel *= np.sqrt((3 * N - 3) / np.sum(vel * vel))
+    eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+    if uniform:
+        eps, sigma = np.ones(N), np.ones(N)
+    return pos, vel, eps, sigma, float(lengths[0])
+
+
+def _build(E, world, pos, vel, atoms, L, dtype=torch.float64, scatter=True):
+    dev = torch.device("cuda", 0)
+    N = pos.shape[0]
+    dd = E.DomainDecomposition([L] * 3, E.domain.rank_grid(world), E.LennardJonesModel(RC, RS), skin=SKIN, dtype=dtype, device=dev)
+    ndt = np.float64 if dtype == torch.float64 else np.float32
+    for r in range(world):
+        # every domain starts from an arbitrary slice of the atoms: the load must hand each to its brick
+        mine = np.arange(r, N, world) if scatter else np.arange(N)[(np.arange(N) * world) // N == r]
+        dd.set_atoms_(r, E.cu(pos[mine].astype(ndt), dev), E.cu(vel[mine].astype(ndt), dev), E.cu(atoms[mine], dev),
+                      torch.from_numpy(mine.astype(np.int64)).to(dev))
+    dd.load_()
+    return dd
+
+
+def _gather(dd, world, N):
+    x, v, f = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3))
+    seen = np.zeros(N, dtype=int)
+    for r in range(world):
+        gid, xr, vr, fr = dd.state(r)
+        gid = gid.cpu().numpy()
+        seen[gid] += 1
+        x[gid], v[gid], f[gid] = xr.cpu().numpy(), vr.cpu().numpy(), fr.cpu().numpy()
+    assert (seen == 1).all(), "every atom is owned by exactly one domain"
+    return x, v, f
+
+
+@pytest.mark.parametrize("world,rebuild_every,langevin,uniform",
+                         [(2, 0, 0, 0), (4, 0, 0, 0), (8, 0, 0, 1), (3, 0, 0, 0), (2, 4, 0, 0), (4, 7, 1, 1), (8, 0, 1, 0), (1, 0, 0, 0)])
+def test_dd_trajectory_matches_oracle(emdee, oracle, world, rebuild_every, langevin, uniform):
+    E = emdee
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, world, pos, vel, atoms, L)
+    if langevin:
+        dd.set_langevin_(*LANGEVIN)
+    c = [dd.counts(r) for r in range(world)]
+    assert sum(k["n_owned"] for k in c) == N and c[0]["n_global"] == N
+    assert all(k["n_ghost"] > 0 for k in c) or world == 1
+    e0 = dd.totals()
+    nsteps = 25
+    dd.step_(13, DT, rebuild_every)                  # two calls: the closing half kick and the re-opening must chain
+    dd.step_(nsteps - 13, DT, rebuild_every)
+    e1 = dd.totals()
+    orc_atoms = oracle.lj_atoms(eps, sigma)
+    if langevin:       # noise keyed by (seed, step number, global atom id): steps are numbered across the chained calls
+        ref = oracle.verlet_langevin(pos, vel, L, oracle.model(RC, RS), orc_atoms, DT, nsteps, *LANGEVIN)
+    else:
+        ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), orc_atoms, DT, nsteps)
+    x, v, f = _gather(dd, world, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(v - ref["v"]).max() < 1e-8
+    assert np.abs(f - ref["f"]).max() < 1e-6 * np.abs(ref["f"]).max()
+    assert e0[0] == pytest.approx(ref["epot"][0], rel=1e-10) and e0[1] == pytest.approx(ref["ekin"][0], rel=1e-10)
+    assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
+    st = dd.stats()
+    assert st["rebuilds"] >= 2
+    if world > 1:
+        assert st["migrated"] > 0                    # the scattered initial slices had to be sorted out
+    dd.close()
+
+
+def test_dd_langevin_single_call_matches_oracle(emdee, oracle):
+    """Noise keyed by global atom id and step number: the decomposed run draws what the undivided run draws."""
+    E = emdee
+    pos, vel, eps, sigma, L = _global_box(E.synthetic)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, 4, pos, vel, atoms, L)
+    dd.set_langevin_(*LANGEVIN)
+    dd.step_(25, DT, 0)
+    ref = oracle.verlet_langevin(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, 25, *LANGEVIN)
+    x, v, f = _gather(dd, 4, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(v - ref["v"]).max() < 1e-8
+    e1 = dd.totals()
+    assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
+
+
+def test_dd_long_run_with_migration_and_batches(emdee, oracle):
+    """Hot box, 120 steps: many displacement-triggered rebuilds, atoms crossing brick faces, queued steps
+    cancelled by a neighbour's request -- and still the undivided trajectory (to the rounding the chaotic
+    dynamics allows over this length) and its conserved energy."""
+    E = emdee
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform=True)
+    vel = vel * np.sqrt(2.0)                            # T* = 2
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, 8, pos, vel, atoms, L, scatter=False)
+    e0 = dd.totals()
+    dd.step_(120, DT, 0)
+    e1 = dd.totals()
+    ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, 120)
+    x, v, f = _gather(dd, 8, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-7
+    assert e1[0] + e1[1] == pytest.approx(ref["epot"][-1] + ref["ekin"][-1], rel=1e-9)
+    assert abs((e1[0] + e1[1]) - (e0[0] + e0[1])) < 2e-4 * abs(e0[0] + e0[1])
+    st = dd.stats()
+    assert st["rebuilds"] >= 8 and st["batches"] >= 20
+    # the engines' neighbour-list builds agree with the decomposition's count
+    assert dd.engine(0).nbr_stats()["builds"] >= st["rebuilds"]
+
+
+def test_dd_fp32_and_bad_arguments(emdee):
+    E = emdee
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform=True)
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, 2, pos, vel, atoms, L, dtype=torch.float32)
+    e0 = dd.totals()
+    dd.step_(40, DT, 0)
+    e1 = dd.totals()
+    assert abs((e1[0] + e1[1]) - (e0[0] + e0[1])) < 5e-4 * abs(e0[0] + e0[1])     # NVE in fp32 storage + pair math
+    with pytest.raises(E.EmDeeError):
+        E.DomainDecomposition([L] * 3, (4, 1, 1), E.LennardJonesModel(RC, RS), device=torch.device("cuda", 0))   # > 3 bricks
+    with pytest.raises(E.EmDeeError):
+        E.DomainDecomposition([5.0] * 3, (2, 1, 1), E.LennardJonesModel(RC, RS), device=torch.device("cuda", 0))   # halo > brick
+    fresh = E.DomainDecomposition([L] * 3, (2, 1, 1), E.LennardJonesModel(RC, RS), device=torch.device("cuda", 0))
+    with pytest.raises(E.EmDeeError):
+        fresh.step_(1, DT)                               # step before load
