@@ -1,8 +1,8 @@
-# EmDeeHip.jl -- drop-in for the hot-path half of EmDee.jl (src/EmDee.jl:3-5 includes vec3.jl,
+# EmDee.jl -- module EmDee, same name as the reference package (src/EmDee.jl:1): drop-in for the hot-path half of EmDee.jl (src/EmDee.jl:3-5 includes vec3.jl,
 # lennard_jones.jl, nonbonded.jl).  No CUDA.jl, no AMDGPU.jl kernel DSL: every kernel is hand-written
 # HIP in libemdee_hip.so, reached with ccall, following the reference's own ccall precedent
 # (src/molecular_graphs.jl:73-80).
-module EmDeeHip
+module EmDee
 
 import Libdl
 
@@ -25,5 +25,6 @@ include("lennard_jones.jl")
 include("nonbonded.jl")
 include("cells.jl")
 include("verlet.jl")
+include("decomposition.jl")
 
 end

@@ -1,8 +1,8 @@
 # The reference's GPU test (test/runtests.jl:19-42,58) against this binding.  Not executed here (no Julia
 # in the image); tests/test_gpu_parity.py::test_compute_nonbonded_reference_test is the executed twin.
 using Test
-include("src/EmDeeHip.jl")
-using .EmDeeHip
+include("src/EmDee.jl")
+using .EmDee
 
 function read_xyz(file)                      # stands in for Chemfiles (test/runtests.jl:20-21)
     lines = readlines(file)
@@ -16,20 +16,20 @@ end
 
 function test_compute_nonbonded(xyz_file, L, cutoff, switch)
     xyz_data = read_xyz(xyz_file)
-    positions = EmDeeHip.cu(Float32.(xyz_data))
+    positions = EmDee.cu(Float32.(xyz_data))
     N = size(xyz_data, 2)
     model = LennardJonesModel(cutoff, switch)
-    atoms = EmDeeHip.cu(fill(LennardJonesAtom(1, 1), N))
+    atoms = EmDee.cu(fill(LennardJonesAtom(1, 1), N))
 
-    forces_ref = EmDeeHip.zeros(Float32, 3, N)
-    energies_ref = EmDeeHip.zeros(Float32, N)
-    virials_ref = EmDeeHip.zeros(Float32, N)
+    forces_ref = EmDee.zeros(Float32, 3, N)
+    energies_ref = EmDee.zeros(Float32, N)
+    virials_ref = EmDee.zeros(Float32, N)
     naively_compute_nonbonded!(forces_ref, energies_ref, virials_ref, positions, L, model, atoms)
 
     tiles = nonbonded_computation_tiles(N, all_pairs=true)
-    forces = EmDeeHip.zeros(Float32, 3, N)
-    energies = EmDeeHip.zeros(Float32, N)
-    virials = EmDeeHip.zeros(Float32, N)
+    forces = EmDee.zeros(Float32, 3, N)
+    energies = EmDee.zeros(Float32, N)
+    virials = EmDee.zeros(Float32, N)
     compute_nonbonded!(forces, energies, virials, positions, L,
                        tiles, model, atoms, Val(FORCES | ENERGIES | VIRIALS))
 
@@ -38,6 +38,6 @@ function test_compute_nonbonded(xyz_file, L, cutoff, switch)
            maximum(abs.(Array(virials) .- Array(virials_ref))) < 1.0f-4
 end
 
-@testset "EmDeeHip[GPU]" begin
+@testset "EmDee[GPU]" begin
     @test test_compute_nonbonded(joinpath(@__DIR__, "..", "..", "tests", "golden", "lj_sample.xyz"), 10, 3, 2.5)
 end
