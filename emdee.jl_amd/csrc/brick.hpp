@@ -122,6 +122,10 @@ struct BrickArgs {
     real lgv_c1;
     // UNI kernels: every atom carries the same LJAtom, so sigma_ij^2 and 4 eps_ij are launch constants
     real uni_sigma2, uni_e4;
+    LJUni<real> uni;           // ... folded into the switch constants for the force-only kernels of the MD loop (lj_pair.hpp)
+    // list entries are tile slots shifted left by idx_shift: single-species boxes store BYTE offsets into the coordinate
+    // planes (slot * sizeof(real); a tile of <= 2048 slots keeps them below 2^16), saving the address shift per pair
+    int idx_shift;
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -152,10 +156,18 @@ struct BrickTables {
 // Single-species fp64 force kernels keep only the three coordinate planes in LDS (24 B per record instead of the
 // 32-byte HBM record): with a fixed plane pitch the three reads of a neighbour share one address register and differ
 // in the instruction's immediate offset, and three workgroups fit a CU where the 32-byte tile allows two.
-constexpr int SOA_SLOTS = 2048;                      // plane pitch in records (16 KB per plane)
+constexpr int SOA_SLOTS = 2048;                      // records a coordinate-plane tile can hold
+// Plane pitch in records.  fp64: one record more than a power of two, so that the x and y reads of a neighbour cannot be
+// merged into one ds_read2st64_b64 (8 LDS-array cycles per wavefront, MI355X_MICROARCH.md LDS table) and stay two
+// ds_read_b64 (2 cycles each) off one address register with immediate offsets.
+#ifndef EMDEE_SOA_PAD
+#define EMDEE_SOA_PAD 1
+#endif
+template <typename real>
+constexpr int soa_pitch() { return SOA_SLOTS + ((sizeof(real) == 8 && EMDEE_SOA_PAD) ? 1 : 0); }
 template <typename real, class Shape, int THREADS>
 static inline size_t brick_force_lds_bytes_soa(int own_cap) {
-    return (size_t)3 * SOA_SLOTS * sizeof(real) + BrickTables<Shape, THREADS>::bytes(own_cap);
+    return (((size_t)3 * soa_pitch<real>() * sizeof(real) + 15) & ~(size_t)15) + BrickTables<Shape, THREADS>::bytes(own_cap);
 }
 
 // bytes of dynamic LDS: force tile = HBM records (+ te plane for fp32); build tile = float4
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
                     const int c = k + (k >= BUILD2_FIELD ? cB : cA);
-                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)c;
+                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
                     e++;
                 }
             }
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     const unsigned bits = (half >> gshift) & gmask;
                     if (pass) {
                         const unsigned e = count + __popc(bits & ltmask);
-                        if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)c;
+                        if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
                     }
                     count += __popc(bits);
                 }
@@ -612,9 +624,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // would shift the base and put the ds_read_b128 gathers off their natural alignment).
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     constexpr bool SOA = UNI && MODE != BRICK_STATS;   // coordinate planes only (see SOA_SLOTS)
+    // force-only single-species kernels (the MD loop): coordinates scaled by 1/sigma in the tile, constants folded (LJUni)
+    constexpr bool FAST = SOA && BITMASK == EMDEE_FORCES && sizeof(real) == 8;   // (fp32: the packed body below)
     Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
-    real *plane = reinterpret_cast<real *>(s_dyn);                       // SOA: x | y | z, SOA_SLOTS apart
-    const size_t tile_bytes = SOA ? (size_t)3 * SOA_SLOTS * sizeof(real) : (size_t)a.tile_cap * sizeof(Rec<real>);
+    real *plane = reinterpret_cast<real *>(s_dyn);                       // SOA: x | y | z, soa_pitch() records apart
+    constexpr int PITCH = soa_pitch<real>();
+    const size_t tile_bytes = SOA ? (((size_t)3 * PITCH * sizeof(real) + 15) & ~(size_t)15) : (size_t)a.tile_cap * sizeof(Rec<real>);
     const size_t te_bytes = (sizeof(real) == 4 && !SOA) ? (((size_t)a.tile_cap * 4 + 15) & ~(size_t)15) : 0;
     float *tile_te = reinterpret_cast<float *>(s_dyn + tile_bytes);   // fp32 only
     BrickTables<Shape, THREADS> T;
@@ -650,7 +665,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         r.x += (real)((sh & 3) - 1) * a.g.len[0];
         r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
         r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
-        if (SOA) { plane[s] = r.x; plane[SOA_SLOTS + s] = r.y; plane[2 * SOA_SLOTS + s] = r.z; }
+        if (FAST) { r.x *= a.uni.inv_sigma; r.y *= a.uni.inv_sigma; r.z *= a.uni.inv_sigma; }
+        if (SOA) { plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z; }
         else tile[s] = r;
         if (sizeof(real) == 4 && !SOA) tile_te[s] = a.te[gp];
     });
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         Rec<real> far;
         const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
         far.x = far.y = far.z = big; far.hs = 0;
-        if (SOA) { plane[0] = big; plane[SOA_SLOTS] = big; plane[2 * SOA_SLOTS] = big; }
+        if (SOA) { plane[0] = big; plane[PITCH] = big; plane[2 * PITCH] = big; }
         else tile[0] = far;
         if (sizeof(real) == 4 && !SOA) tile_te[0] = 0.f;
     }
@@ -677,8 +693,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // Loop-invariant operands that would otherwise be re-materialised from SGPRs inside every pair
     // iteration (a VOP3 instruction takes one scalar source): keep them in VGPRs.
     LJModel<real> mdl = a.model;
-    if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k18));
+    LJUni<real> uni = a.uni;
+    if (FAST) asm volatile("" : "+v"(uni.nx0), "+v"(uni.idl2), "+v"(uni.p4), "+v"(uni.p3), "+v"(uni.p0));
+    else if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k18));
     else asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
+    // SOA kernels index the coordinate planes with the BYTE offsets stored in the list; the others decode the slot
+    const unsigned char *plane_b = reinterpret_cast<const unsigned char *>(s_dyn);
+    constexpr int PLANE_BYTES = PITCH * (int)sizeof(real);
 
     // ---- own atoms: one G-lane group per atom; the NEXT atom's indices are fetched meanwhile -----
     const int gl = lane & (G - 1);                            // lane inside the group
@@ -715,7 +736,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         nxt = fetch(o + NGROUPS);
         const int wm = wave_group_max<G>(m);
         real xi, yi, zi, hs_i, te_i;
-        if (SOA) { xi = plane[ti]; yi = plane[SOA_SLOTS + ti]; zi = plane[2 * SOA_SLOTS + ti]; hs_i = te_i = 0; }
+        if (SOA) { xi = plane[ti]; yi = plane[PITCH + ti]; zi = plane[2 * PITCH + ti]; hs_i = te_i = 0; }
         else tile_load<real>(tile, tile_te, ti, xi, yi, zi, hs_i, te_i);
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
         real vx = 0, vy = 0, vz = 0, bx = 0, by = 0, bz = 0, imv = 1, nx = 0, ny = 0, nz = 0;
@@ -734,14 +755,14 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         constexpr bool PACKED = SOA && sizeof(real) == 4;
         auto block2 = [&](const uint4 &q, int b0) {
             if constexpr (PACKED) {
-                const float *pl = reinterpret_cast<const float *>(plane);
 #pragma unroll
                 for (int t = 0; t < EPL; t += 2) {
                     if (b0 + t * G >= wm) break;              // wave-uniform; the partner entry t + 1 is a sentinel at worst
-                    const int sa = pick16(q, t), sb = pick16(q, t + 1);
-                    const f32x2 dx = f32x2{(float)xi, (float)xi} - f32x2{pl[sa], pl[sb]};
-                    const f32x2 dy = f32x2{(float)yi, (float)yi} - f32x2{pl[SOA_SLOTS + sa], pl[SOA_SLOTS + sb]};
-                    const f32x2 dz = f32x2{(float)zi, (float)zi} - f32x2{pl[2 * SOA_SLOTS + sa], pl[2 * SOA_SLOTS + sb]};
+                    const unsigned char *pa = plane_b + pick16(q, t), *pb = plane_b + pick16(q, t + 1);   // byte offsets
+                    auto ld = [](const unsigned char *p, int plane_no) { return *reinterpret_cast<const float *>(p + plane_no * PLANE_BYTES); };
+                    const f32x2 dx = f32x2{(float)xi, (float)xi} - f32x2{ld(pa, 0), ld(pb, 0)};
+                    const f32x2 dy = f32x2{(float)yi, (float)yi} - f32x2{ld(pa, 1), ld(pb, 1)};
+                    const f32x2 dz = f32x2{(float)zi, (float)zi} - f32x2{ld(pa, 2), ld(pb, 2)};
                     const f32x2 r2 = dx * dx + dy * dy + dz * dz;
                     const bool ina = r2.x < (float)a.model.rc2, inb = r2.y < (float)a.model.rc2;   // strict test (Q2)
                     if (ina | inb) {
@@ -776,14 +797,24 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             for (int t = 0; t < EPL; t++) {
                 if (b0 + t * G >= wm) break;                  // wave-uniform; entries past a row's end are sentinels
                 {
-                    const int sj = pick16(q, t);
+                    const int sj = SOA ? pick16(q, t) : (pick16(q, t) >> a.idx_shift);
                     real xj, yj, zj, hs_j, te_j;
-                    if (SOA) { xj = plane[sj]; yj = plane[SOA_SLOTS + sj]; zj = plane[2 * SOA_SLOTS + sj]; hs_j = te_j = 0; }
-                    else tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
+                    if (SOA) {
+                        const unsigned char *pj = plane_b + sj;          // byte offset: three reads off one address register
+                        xj = *reinterpret_cast<const real *>(pj);
+                        yj = *reinterpret_cast<const real *>(pj + PLANE_BYTES);
+                        zj = *reinterpret_cast<const real *>(pj + 2 * PLANE_BYTES);
+                        hs_j = te_j = 0;
+                    } else tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
                     const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const real r2 = dx * dx + dy * dy + dz * dz;
                     if (MODE == BRICK_STATS) {
                         st_inside += (b0 + t * G + gl < m && r2 < a.model.rc2) ? 1ull : 0ull;
+                    } else if (FAST) {
+                        if (r2 < uni.rc2) {                   // strict test (Q2), in scaled coordinates
+                            const real wr2 = lj_force_over_r2_uni(r2, uni);
+                            fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
+                        }
                     } else if (r2 < a.model.rc2) {            // strict test (Q2)
                         const real inv_r2 = fast_rcp(r2);
                         if (BITMASK == EMDEE_FORCES) {        // the MD loop's kernels: W / r2 directly (lj_pair.hpp)
@@ -832,6 +863,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             // all lanes are active here: DPP reductions see every lane of the group
             if (BITMASK & EMDEE_FORCES) {
                 fx = group_sum_to_last<G>(fx); fy = group_sum_to_last<G>(fy); fz = group_sum_to_last<G>(fz);
+                if (FAST) { fx *= uni.inv_sigma; fy *= uni.inv_sigma; fz *= uni.inv_sigma; }   // back from scaled coordinates
             }
             if (BITMASK & EMDEE_ENERGIES) e = group_sum_to_last<G>(e);
             if (BITMASK & EMDEE_VIRIALS) w = group_sum_to_last<G>(w);
@@ -848,7 +880,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     if (a.noise) { vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz; }
                     a.vel_next[p] = vx; a.vel_next[a.pitch + p] = vy; a.vel_next[2 * a.pitch + p] = vz;
                     Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
-                    r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz;
+                    if (FAST) { r.x += a.dt * vx; r.y += a.dt * vy; r.z += a.dt * vz; }   // (the tile holds scaled coordinates)
+                    else { r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz; }
                     a.rec_next[p] = r;
                     const real ex = r.x - bx, ey = r.y - by, ez = r.z - bz;
                     if (ex * ex + ey * ey + ez * ez > a.thr2) *a.trigger = 1;

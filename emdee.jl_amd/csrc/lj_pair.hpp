@@ -96,6 +96,63 @@ __device__ __forceinline__ real lj_force_over_r2(real r2, real inv_r2, const LJM
     return (d * g6) * inv_r2 + em * q;
 }
 
+// ---- single-species MD kernels: the same function with everything constant folded into the launch constants ------
+// All atoms carry one LJAtom, so sigma and 4 eps are launch constants.  The kernel works in coordinates scaled by
+// 1/sigma (done once per record while the tile is staged): s^-2 is then 1/r'^2 itself; 4 eps is folded into the
+// constants of the switch polynomials; 6 g = 6 - 60 x^3 + 90 x^4 - 36 x^5 in Horner form and -r g'/r^2 = 60 idl2
+// (x - x^2)^2 share nothing but x; and x = clamp(r'^2 idl2' - x0, 0, 1) is ONE instruction (the VOP3 clamp bit).
+// The caller's test r'^2 < rc'^2 keeps x < 1 except when the fused multiply-add rounds to exactly 1.0, where this
+// form yields 0 (the limit of the function as r -> rc) and not the reference's x == 1 -> 0.5 quirk (Q2): the
+// all-pairs kernels and every kernel that outputs E or W keep the literal clamp.
+// Returns (W g + E (-r g')) / r'^2 in units where the caller still owes one factor 1/sigma on the summed force.
+template <typename real>
+struct LJUni {
+    real rc2;          // rc^2 / sigma^2
+    real idl2;         // idl2 sigma^2
+    real nx0;          // -(rs2 idl2)
+    real p0, p3, p4, p5;   // 4 eps (6, -60, 90, -36)
+    real c60;          // 4 eps 60 idl2 sigma^2
+    real inv_sigma;    // 1 / sigma
+};
+template <typename real>
+static inline LJUni<real> make_uni(const LJModel<real> &m, real sigma, real e4) {
+    LJUni<real> u;
+    const real s2 = sigma * sigma;
+    u.rc2 = m.rc2 / s2;
+    u.idl2 = m.idl2 * s2;
+    u.nx0 = -m.x0;
+    u.p0 = (real)6 * e4; u.p3 = (real)-60 * e4; u.p4 = (real)90 * e4; u.p5 = (real)-36 * e4;
+    u.c60 = e4 * (real)60 * u.idl2;
+    u.inv_sigma = (real)1 / sigma;
+    return u;
+}
+__device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <typename real>
+__device__ __forceinline__ real lj_force_over_r2_uni(real r2, const LJUni<real> &m) {
+    const real x = fma_clamp01(r2, m.idl2, m.nx0);
+    const real inv = fast_rcp(r2);                                     // s^-2 in scaled coordinates
+    const real s6 = inv * inv * inv;                                   // a / 4 eps
+    const real b = s6 * s6;                                            // b / 4 eps
+    const real d = (real)2 * b - s6;                                   // W / (6 . 4 eps)   (contracted to one fma)
+    const real em = b - s6;                                            // E / 4 eps
+    const real x2 = x * x;
+    real t = m.p5 * x + m.p4;
+    t = t * x + m.p3;
+    const real g6 = (x2 * x) * t + m.p0;                               // 4 eps 6 g
+    const real y = x - x * x;                                          // x (1 - x)
+    const real q = (m.c60 * y) * y;                                    // 4 eps (-r g') / r'^2
+    return em * q + (d * g6) * inv;
+}
+
 // ---- two pairs per lane in packed fp32 (plain fp32 VALU instructions issue at the fp64 rate on gfx950) ------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

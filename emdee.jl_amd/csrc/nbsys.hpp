@@ -298,6 +298,8 @@ struct NbSystem {
         a.vel = vel.ptr; a.vel_next = vel2.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
         a.kick_c = (real)step_c; a.dt = (real)step_dt;
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
+        a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
+        a.idx_shift = idx_shift;
         a.thr2 = (real)(0.25 * skin * skin);
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
@@ -312,7 +314,7 @@ struct NbSystem {
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
             // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
-            if (uniform_atoms && tile_cap <= SOA_SLOTS) {
+            if (uniform_atoms && tile_cap <= SOA_SLOTS && idx_shift == PLANE_SHIFT) {
                 launch_brick_kernel_impl<V, MODE, BM, true>();
                 return;
             }
@@ -433,6 +435,7 @@ struct NbSystem {
             if (!plan_bricks()) { variant = 0; plan_bricks(); }
         }
         if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
+        idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !std::getenv("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 3 * sizeof(int), stream()));
@@ -501,7 +504,10 @@ struct NbSystem {
     int force_phase = 0;
     double step_c = 0.0, step_dt = 0.0;
     bool uniform_atoms = false;            // every atom has the same LJAtom (checked when a state is loaded)
-    double uni_sigma2 = 0.0, uni_e4 = 0.0;
+    double uni_sigma2 = 0.0, uni_e4 = 0.0, uni_sigma = 1.0;
+    // neighbour entries = tile slot << idx_shift; single-species boxes store byte offsets into the coordinate planes
+    static constexpr int PLANE_SHIFT = sizeof(real) == 8 ? 3 : 2;
+    int idx_shift = 0;
 
     // Are all LJAtom records identical?  (One small kernel + an 8-byte read-back per load.)
     void detect_uniform_atoms(const emdee_lj_atom *atoms) {
@@ -513,10 +519,11 @@ struct NbSystem {
         EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 5, flags.ptr + 5, sizeof(int), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
-        if (ctx->host_flags[5] == 0) {
+        if (ctx->host_flags[5] == 0 && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
             // the same fp operations as the per-pair path: (hs + hs)^2 and te * te in the kernel's type
             const real sg = (real)first.half_sigma + (real)first.half_sigma;
+            uni_sigma = (double)sg;
             uni_sigma2 = (double)(sg * sg);
             uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
         }
@@ -733,9 +740,10 @@ struct NbSystem {
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 6 * sizeof(int), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
         uniform_atoms = false;
-        if (ctx->host_flags[5] == 0 && !std::getenv("EMDEE_NO_UNIFORM")) {
+        if (ctx->host_flags[5] == 0 && !std::getenv("EMDEE_NO_UNIFORM") && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
             const real sg = (real)first.half_sigma + (real)first.half_sigma;
+            uni_sigma = (double)sg;
             uni_sigma2 = (double)(sg * sg);
             uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
         }
