@@ -927,6 +927,36 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     }
 }
 
+// Debug/verification accessor: the neighbour rows as CALLER ids (tile-local slots decoded through the brick's tables),
+// counts[i] entries at out[i * capacity ...], in list order.  One workgroup per brick, like the force kernels.
+template <typename real, class Shape, int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int *__restrict__ counts, int *__restrict__ out,
+                                                          int capacity) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    BrickTables<Shape, THREADS> T;
+    T.carve(s_dyn);
+    int bxi, byi, bzi, tile_n, n_own;
+    if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
+    for (int o = threadIdx.x; o < n_own; o += THREADS) {
+        int ti, p;
+        brick_locate(T, o, ti, p);
+        const int i = a.perm[p];
+        if (i >= a.n_owned) continue;
+        const int m = a.cnt[p];
+        counts[i] = m;
+        const unsigned short *row = a.nbr + (size_t)p * a.stride;
+        for (int e = 0; e < m && e < capacity; e++) {
+            const int sl = (int)row[row_position<G>((unsigned)e)] >> a.idx_shift;
+            int lo = 0, hi = Shape::NTC;                  // tile cell with off[tc] <= sl < off[tc + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (T.off[mid] <= sl) lo = mid; else hi = mid;
+            }
+            out[(size_t)i * capacity + e] = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+        }
+    }
+}
+
 // Largest tile (brick + halo population) and largest own population over all bricks -> sizes the
 // dynamic LDS of the brick kernels.  out[0] = max tile, out[1] = max own, out[2] = most atoms in three
 // consecutive cells of a tile row (what one group of the build kernel scans per row).

@@ -245,6 +245,13 @@ int32_t emdee_nbr_count_pairs(emdee_nbr *nbr, int64_t *pairs_in_cutoff) {
     return guarded([&] { REQUIRE_PTR(nbr, "nbr"); REQUIRE_PTR(pairs_in_cutoff, "pairs_in_cutoff"); nbr->impl->count_pairs(pairs_in_cutoff); });
 }
 
+int32_t emdee_nbr_list(emdee_nbr *nbr, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity) {
+    return guarded([&] { REQUIRE_PTR(nbr, "nbr"); nbr->impl->export_list(counts_dev, neighbors_dev, capacity); });
+}
+int32_t emdee_md_nbr_list(emdee_md *md, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->export_list(counts_dev, neighbors_dev, capacity); });
+}
+
 int32_t emdee_compute_nonbonded(emdee_ctx *ctx, void *forces_dev, void *energies_dev, void *virials_dev,
                                 const void *positions_dev, double L, emdee_nbr *nbr, emdee_lj_model model,
                                 const emdee_lj_atom *atoms_dev, int32_t bitmask, int32_t precision) {

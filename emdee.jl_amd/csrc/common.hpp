@@ -28,6 +28,7 @@ struct Failure {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) {                                                                  \
             ::emdee::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            (void)hipGetLastError(); /* reported here: do not leave it for an unrelated later call */ \
             throw ::emdee::Failure{EMDEE_ERR_HIP};                                               \
         }                                                                                        \
     } while (0)

@@ -20,6 +20,7 @@ struct INbr {
                          const emdee_lj_model &model, const emdee_lj_atom *atoms, int bitmask) = 0;
     virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;
     virtual void count_pairs(int64_t *pairs) = 0;
+    virtual void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) = 0;
 };
 
 struct IMd {
@@ -40,6 +41,7 @@ struct IMd {
     virtual void energies(double out[3]) = 0;
     virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;
     virtual void count_pairs(int64_t *pairs) = 0;
+    virtual void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) = 0;
     virtual void profile(bool enable) = 0;
     virtual void kernel_time(int kernel, double *total_ms, int64_t *launches) = 0;
     virtual void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) = 0;

@@ -118,6 +118,10 @@ struct NbrImpl : INbr {
         use_device(sys.ctx);
         sys.list_stats(true, nullptr, nullptr, pairs);
     }
+    void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) override {
+        use_device(sys.ctx);
+        sys.export_list(counts, neighbors, capacity);
+    }
 };
 
 // ------------------------------------------------------------------------------------ velocity-Verlet
@@ -268,6 +272,10 @@ struct MdImpl : IMd {
     void count_pairs(int64_t *pairs) override {
         use_device(sys.ctx);
         sys.list_stats(true, nullptr, nullptr, pairs);
+    }
+    void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) override {
+        use_device(sys.ctx);
+        sys.export_list(counts, neighbors, capacity);
     }
     void profile(bool enable) override {
         sys.profiling = enable;

@@ -708,6 +708,18 @@ __global__ void k_unpack_ghosts(int n, int first_id, const int *__restrict__ inv
     rec[p] = r;
 }
 
+// neighbour rows of the direct (int32, cell-order slot) list as caller ids
+static __global__ void k_export_rows(int n, int n_owned, const int *__restrict__ perm, const int *__restrict__ nbr, int stride,
+                                     const int *__restrict__ cnt, int *__restrict__ counts, int *__restrict__ out, int capacity) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = perm[p];
+    if (i >= n_owned) return;
+    const int m = cnt[p];
+    counts[i] = m;
+    for (int e = 0; e < m && e < capacity; e++) out[(size_t)i * capacity + e] = perm[nbr[(size_t)p * stride + e]];
+}
+
 // ------------------------------------------------------------------------------------ reductions
 // Deterministic two-stage sums in fp64 (mixed precision: fp32 per-atom values, fp64 totals).
 constexpr int RED_BLOCK = 256;

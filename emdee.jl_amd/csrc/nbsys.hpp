@@ -417,6 +417,15 @@ struct NbSystem {
     // ---------------------------------------------------------------- neighbour list
     bool brick_active = false;
 
+    bool build_fits_lds() {
+        bool ok = true;
+        with_brick_variant(variant, [&](auto v) {
+            using V = decltype(v);
+            ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
+        });
+        return ok;
+    }
+
     void build_list() {
         const int n = n_total;
         if (stride == 0) {
@@ -435,6 +444,9 @@ struct NbSystem {
             if (!plan_bricks()) { variant = 0; plan_bricks(); }
         }
         if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
+        // the build kernel's LDS (fp32 tile + tables + one row buffer per lane group) must fit as well: very dense or
+        // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
+        if (brick_active && !build_fits_lds()) brick_active = false;
         idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !std::getenv("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
@@ -486,6 +498,7 @@ struct NbSystem {
             }
             stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
             if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;
+            if (brick_active && !build_fits_lds()) { brick_active = false; idx_shift = 0; btab_valid = false; }
         }
         EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
     }
@@ -705,6 +718,27 @@ struct NbSystem {
         if (listed) *listed = (int64_t)h[0];
         if (max_count) *max_count = (int32_t)h[1];
         if (inside) *inside = (int64_t)(h[2] / 2);   // full list: every pair appears twice
+    }
+
+    // neighbour rows as caller ids (verification accessor): counts[n_owned], out[n_owned x capacity]
+    void export_list(int *counts, int *out, int capacity) {
+        EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
+        EMDEE_REQUIRE(counts && out && capacity > 0, EMDEE_ERR_INVALID, "export_list: bad arguments");
+        if (n_total == 0) return;
+        if (brick_active) {
+            with_brick_variant(variant, [&](auto v) {
+                using V = decltype(v);
+                auto kernel = k_brick_export<real, typename V::Shape, V::THREADS, V::G>;
+                using BT = BrickTables<typename V::Shape, V::THREADS>;
+                const size_t lds = BT::bytes(0);
+                hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds, stream(), brick_args(), counts, out,
+                                   capacity);
+            });
+        } else {
+            hipLaunchKernelGGL(k_export_rows, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned, perm.ptr, nbr.ptr,
+                               stride, cnt.ptr, counts, out, capacity);
+        }
+        EMDEE_HIP_CHECK(hipGetLastError());
     }
 
     // ---------------------------------------------------------------- caller-order copies

@@ -80,6 +80,17 @@ class NeighborTiles:
         _lib.call("emdee_nbr_count_pairs", self._handle, C.byref(n))
         return n.value
 
+    def neighbor_lists(self):
+        """The current list as caller ids: (counts (N,) int32, neighbors (N, capacity) int32), rows in list order
+        (verification accessor: the library itself stores 16-bit tile-local slots)."""
+        import torch
+        cap = max(self.stats()["capacity"], 1)
+        dev = self._ctx.device
+        counts = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        nb = torch.full((self.N, cap), -1, dtype=torch.int32, device=dev)
+        _lib.call("emdee_nbr_list", self._handle, C.c_void_p(counts.data_ptr()), C.c_void_p(nb.data_ptr()), cap)
+        return counts, nb
+
     def close(self):
         if self._handle is not None:
             _lib.call("emdee_nbr_destroy", self._handle)

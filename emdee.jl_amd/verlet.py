@@ -136,6 +136,14 @@ class VelocityVerlet:
         _lib.call("emdee_md_count_pairs", self._handle, C.byref(n))
         return n.value
 
+    def neighbor_lists(self):
+        """The current list as caller ids: (counts (n_owned,), neighbors (n_owned, capacity)) int32, list order."""
+        cap = max(self.nbr_stats()["capacity"], 1)
+        counts = torch.zeros(self.n_owned, dtype=torch.int32, device=self.device)
+        nb = torch.full((self.n_owned, cap), -1, dtype=torch.int32, device=self.device)
+        _lib.call("emdee_md_nbr_list", self._handle, C.c_void_p(counts.data_ptr()), C.c_void_p(nb.data_ptr()), cap)
+        return counts, nb
+
     def profile_(self, enable=True):
         _lib.call("emdee_md_profile", self._handle, int(bool(enable)))
 

@@ -137,6 +137,13 @@ int32_t emdee_nbr_stats(emdee_nbr *nbr, int64_t *builds, int64_t *listed, int32_
 /* number of pairs with r^2 < rc^2 in the current list (each pair counted once). Blocking. */
 int32_t emdee_nbr_count_pairs(emdee_nbr *nbr, int64_t *pairs_in_cutoff);
 
+/* Verification accessor: the current list as CALLER ids.  counts_dev[i] = entries of atom i's row (skin entries
+ * included), neighbors_dev[i * capacity + k] = its k-th neighbour, k < min(counts, capacity); capacity >= the
+ * `capacity` of emdee_nbr_stats returns every row whole.  Owned atoms only; ghosts appear as neighbours.
+ * (The list itself stores 16-bit tile-local slots; this decodes them through the brick tables.) */
+int32_t emdee_nbr_list(emdee_nbr *nbr, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity);
+int32_t emdee_md_nbr_list(emdee_md *md, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity);
+
 /* compute_nonbonded!(forces, energies, virials, positions, L, tiles, model, atoms, Val(bitmask))
  * -- src/nonbonded.jl:109-120 -- O(N) neighbour-list path, EMDEE_CUTOFF semantics.
  * Outputs not selected by bitmask may be NULL and are left untouched; selected outputs are
