@@ -625,7 +625,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     constexpr bool SOA = UNI && MODE != BRICK_STATS;   // coordinate planes only (see SOA_SLOTS)
     // force-only single-species kernels (the MD loop): coordinates scaled by 1/sigma in the tile, constants folded (LJUni)
-    constexpr bool FAST = SOA && BITMASK == EMDEE_FORCES && sizeof(real) == 8;   // (fp32: the packed body below)
+    constexpr bool FAST = SOA && BITMASK == EMDEE_FORCES;
     Rec<real> *tile = reinterpret_cast<Rec<real> *>(s_dyn);
     real *plane = reinterpret_cast<real *>(s_dyn);                       // SOA: x | y | z, soa_pitch() records apart
     constexpr int PITCH = soa_pitch<real>();
@@ -764,6 +764,15 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     const f32x2 dy = f32x2{(float)yi, (float)yi} - f32x2{ld(pa, 1), ld(pb, 1)};
                     const f32x2 dz = f32x2{(float)zi, (float)zi} - f32x2{ld(pa, 2), ld(pb, 2)};
                     const f32x2 r2 = dx * dx + dy * dy + dz * dz;
+                    if constexpr (FAST) {                     // scaled coordinates, constants folded (LJUni)
+                        const bool ina = r2.x < (float)uni.rc2, inb = r2.y < (float)uni.rc2;
+                        if (ina | inb) {
+                            f32x2 wr2 = lj_force_over_r2_uni2(r2, uni);
+                            wr2 = f32x2{ina ? wr2.x : 0.f, inb ? wr2.y : 0.f};
+                            pfx += wr2 * dx; pfy += wr2 * dy; pfz += wr2 * dz;
+                        }
+                        continue;
+                    }
                     const bool ina = r2.x < (float)a.model.rc2, inb = r2.y < (float)a.model.rc2;   // strict test (Q2)
                     if (ina | inb) {
                         const f32x2 inv = {fast_rcp(r2.x), fast_rcp(r2.y)};

@@ -194,6 +194,28 @@ __device__ __forceinline__ f32x2 lj_force_over_r2_2(f32x2 r2, f32x2 inv_r2, cons
     const f32x2 q = m.c60 * (x2 * u2);
     return (d * g6) * inv_r2 + em * q;
 }
+// lj_force_over_r2_uni on two independent pairs at once (scaled coordinates, constants folded; see LJUni)
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 lj_force_over_r2_uni2(f32x2 r2, const LJUni<float> &m) {
+    const f32x2 x = pk_fma_clamp01(r2, f32x2{m.idl2, m.idl2}, f32x2{m.nx0, m.nx0});
+    const f32x2 inv = {fast_rcp(r2.x), fast_rcp(r2.y)};
+    const f32x2 s6 = inv * inv * inv;
+    const f32x2 b = s6 * s6;
+    const f32x2 d = 2.0f * b - s6;
+    const f32x2 em = b - s6;
+    const f32x2 x2 = x * x;
+    f32x2 t = m.p5 * x + m.p4;
+    t = t * x + m.p3;
+    const f32x2 g6 = (x2 * x) * t + m.p0;
+    const f32x2 y = x - x * x;
+    const f32x2 q = (m.c60 * y) * y;
+    return em * q + (d * g6) * inv;
+}
+__device__ __forceinline__ f32x2 lj_force_over_r2_uni2(f32x2, const LJUni<double> &) { return f32x2{0.f, 0.f}; }
 __device__ __forceinline__ f32x2 lj_force_over_r2_2(f32x2, f32x2, const LJModel<double> &, f32x2, f32x2) { return f32x2{0.f, 0.f}; }
 // (double instantiations never call it; the overload keeps `if constexpr` branches well-formed)
 __device__ __forceinline__ void lj_interaction_pair2(f32x2, f32x2, const LJModel<double> &, f32x2, f32x2, f32x2 &, f32x2 &) {}
