@@ -486,6 +486,137 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         return pass;
     };
     auto in_range = [&](const float4 &qi, int p, int c, int tcr) -> bool { return in_range_q(qi, tile[c], p, c, tcr); };
+    if constexpr (ALG == 3) {
+        // ALG 2 with a leaner candidate loop (the build is VALU-issue bound: 2.7 G wave-instructions per rebuild at
+        // 10^7 atoms, profiles/r02): the trip count of a tile row is made WAVE-uniform (the longest chunk in the
+        // wavefront; a lane whose chunk is shorter tests slots past its chunk and drops those bits afterwards), so
+        // the loop needs no per-lane exit bookkeeping on the execution mask; the hit bit is shifted in by the carry
+        // input of one add (v_cmp -> vcc, v_addc: bits = 2 bits + hit); and the squared distance is accumulated
+        // starting from -r_list^2, so "surely inside" and "inside the rounding band" are compares against +-margin.
+        static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
+        constexpr int NROWS = 9, NWORDS = (NROWS + 1) / 2;
+        constexpr bool BAND = sizeof(real) == 8;              // fp32 boxes: the fp32 test is the definition of the set
+#ifndef EMDEE_BUILD_UNROLL
+#define EMDEE_BUILD_UNROLL 2
+#endif
+        constexpr int UNR = EMDEE_BUILD_UNROLL;
+        float nrl2 = -rl2, nmargin_v = BAND ? -a.margin : 0.f, margin_v = a.margin;
+        asm volatile("" : "+v"(nrl2), "+v"(nmargin_v), "+v"(margin_v));   // loop-invariant operands stay in VGPRs
+        for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
+            const int o = ob + gid;
+            const bool have = o < n_own;
+            int ti = 0, p = 0, oc = 0;
+            if (have) oc = brick_locate(T, o, ti, p);
+            const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+            const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
+            const float4 qi = tile[ti];
+            unsigned short *row = a.nbr + (size_t)p * a.stride;
+            for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
+            unsigned word[NWORDS];
+            int cbase[NROWS];
+#pragma unroll
+            for (int r = 0; r < NROWS; r++) {
+                const int dy = r % 3 - 1, dz = r / 3 - 1;
+                const int tcr = ox + TX * ((oy + 1 + dy) + TY * (oz + 1 + dz));   // cell x-1 of that tile row
+                const int c0 = T.off[tcr];
+                const int span = act ? T.off[tcr + 3] - c0 : 0;                    // cells x-1, x, x+1: contiguous
+                const int chunk = (span + G - 1) / G;                               // <= BUILD2_FIELD (host check)
+                const int first = gl * chunk;
+                const int lim = min(chunk, span - first);                           // my candidates; may be <= 0
+                const int cb = c0 + first;
+                cbase[r] = (r & 1) ? cb - BUILD2_FIELD : cb;
+                const int trips = (wave_group_max<1>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar; the loop is unrolled UNR times
+                unsigned bits = 0;
+                const float4 *cand = tile + cb;
+                // one test: the hit bit of candidate q (slot index c, chunk position k) is shifted into `bits`
+                auto test = [&](const float4 &q, int k) {
+                    const float dx = qi.x - q.x, dyy = qi.y - q.y, dzz = qi.z - q.z;
+                    float t = __builtin_fmaf(dx, dx, nrl2);                         // d^2 - r_list^2
+                    t = __builtin_fmaf(dyy, dyy, t);
+                    t = __builtin_fmaf(dzz, dzz, t);
+                    if constexpr (BAND) {
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabsf(t) <= margin_v) != 0, 0)) {
+                            // rounding band: decided with the exact fp64 records, for the lanes concerned (and only for
+                            // slots of the lane's own chunk: what lies past it is dropped below and may not be a record)
+                            if (__builtin_fabsf(t) <= margin_v && k < lim) {
+                                const int c = cb + k;
+                                const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
+                                const int sh = T.shift[tc];
+                                const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(q.w)];
+                                const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
+                                const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
+                                const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
+                                t = (ex * ex + ey * ey + ez * ez < a.rlist2) ? -1.f : 1.f;
+                            }
+                        }
+                    }
+                    // (keeps the whole 16-byte record alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
+                    if constexpr (!BAND) asm volatile("" : : "v"(q.w));
+                    // fp32 boxes (margin 0): the sign of this fused sum IS the definition of the listed set
+                    asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(bits) : "v"(t), "v"(nmargin_v) : "vcc");
+                };
+                float4 q0 = cand[0];                                                // candidates in flight: UNR + 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int k = 0; k < trips; k += UNR) {                              // (reads past the chunk / the tile: harmless)
+                    float4 qn[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) qn[u] = cand[k + 1 + u];
+                    test(q0, k);
+#pragma unroll
+                    for (int u = 0; u + 1 < UNR; u++) test(qn[u], k + 1 + u);
+                    q0 = qn[UNR - 1];
+                }
+                // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
+                bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & ((1u << lim) - 1u)) : 0u;
+                if (r == 4) {                                                       // the atom itself
+                    const int ks = ti - cb;
+                    if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
+                }
+                if (r & 1) word[r / 2] |= bits << BUILD2_FIELD;
+                else word[r / 2] = bits;
+            }
+            // ---- phase 2 (as ALG 2): prefix over the lanes of the group, then every lane emits its hits --------
+            int mine = 0;
+#pragma unroll
+            for (int w = 0; w < NWORDS; w++) mine += __popc(word[w]);
+            int incl = mine;
+            {
+                int t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR1, 0xf, 0xf, true);
+                incl += gl >= 1 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR2, 0xf, 0xf, true);
+                incl += gl >= 2 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR4, 0xf, 0xf, true);
+                incl += gl >= 4 ? t : 0;
+                if (G == 16) {
+                    t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR8, 0xf, 0xf, true);
+                    incl += gl >= 8 ? t : 0;
+                }
+            }
+            unsigned e = (unsigned)(incl - mine);
+#pragma unroll
+            for (int w = 0; w < NWORDS; w++) {
+                unsigned W = word[w];
+                const int cA = cbase[2 * w], cB = (2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0;
+                while (W) {
+                    const int k = __ffs((int)W) - 1;
+                    W &= W - 1;
+                    const int c = k + (k >= BUILD2_FIELD ? cB : cA);
+                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
+                    e++;
+                }
+            }
+            if (have) {
+                for (int c = gl * EPL; c < a.stride; c += G * EPL)
+                    *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
+                if (gl == G - 1) {                            // the last lane's inclusive prefix is the row length
+                    a.cnt[p] = act ? (int)min((unsigned)incl, ustride) : 0;
+                    if ((unsigned)incl > ustride) atomicMax(&a.flags[0], incl);
+                }
+            }
+        }
+        return;
+    }
     if constexpr (ALG == 2) {
         static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
         constexpr int NROWS = 9, NWORDS = (NROWS + 1) / 2;

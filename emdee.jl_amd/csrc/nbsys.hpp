@@ -109,6 +109,7 @@ struct NbSystem {
     int tile_cap = 0, own_cap = 0, row_block = 1;
     int build_alg = 1;                    // k_brick_build ALG (2 = two-phase; 1 when a tile row is too crowded for it)
     bool force_build1 = false;            // EMDEE_BUILD_ALG=1: A/B switch
+    int build_alg_pref = 3;               // EMDEE_BUILD_ALG=2: the two-phase build with the per-lane candidate loop
     size_t lds_bytes = 0, lds_build_bytes = 0;
     float build_margin = 0.f;
 
@@ -129,7 +130,7 @@ struct NbSystem {
             variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
             variant_forced = true;
         }
-        if (const char *e = std::getenv("EMDEE_BUILD_ALG")) force_build1 = std::atoi(e) == 1;
+        if (const char *e = std::getenv("EMDEE_BUILD_ALG")) { force_build1 = std::atoi(e) == 1; if (std::atoi(e) == 2) build_alg_pref = 2; }
         if (const char *e = std::getenv("EMDEE_RUN_AHEAD")) run_ahead = std::max(1, std::min(RUN_AHEAD, std::atoi(e)));
     }
 
@@ -395,7 +396,7 @@ struct NbSystem {
             if (std::getenv("EMDEE_DEBUG_PLAN"))
                 std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d, own_cap %d, max 3-cell span %d\n", bgrid.nb[0],
                              bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
-            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? 2 : 1;
+            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
@@ -472,6 +473,7 @@ struct NbSystem {
                     auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 1, V::G>;
                     if constexpr (V::GB == 8 || V::GB == 16) {
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
+                        if (build_alg == 3) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 3, V::G>;
                     }
                     lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
                     allow_big_lds(kernel, lds_build_bytes);
