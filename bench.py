@@ -77,6 +77,10 @@ def parse_args():
     ap.add_argument("--domains", type=int, default=0,
                     help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
                          "process on cuda:0 (device-to-device halo copies instead of RCCL)")
+    ap.add_argument("--target-cells", type=int, default=-1,
+                    help="native decomposition, strong scaling: also time a second, larger box of this many fcc cells per side and "
+                         "report it as `target_box`.  Default (-1): the north-star target box (293 -> 100,615,028 atoms) on "
+                         "N > 1 runs of the default 136-cell box; 0 = skip")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same --cells^3x4 box on N GPUs (default); weak = one such brick per GPU")
     return ap.parse_args()
@@ -382,6 +386,51 @@ def main():
                                          "frac_at_profiled_clock": t.get("frac_at_profiled_clock")}
             except Exception:
                 pass
+    # ---- the north-star target box (>= 10^8 atoms) on the same ranks: a second, smaller measurement riding on the N > 1
+    # runs, so that the driver's 1/2/4/8-GPU sweep also yields the strong-scaling curve of the target size.  `value` above
+    # stays the BASELINE metric (the 10^7-atom box); a failure here is reported inside the object and changes nothing else.
+    target_cells = args.target_cells
+    if target_cells < 0:
+        target_cells = 293 if (world > 1 and args.cells == 136 and not args.mixture and args.langevin == 0.0) else 0
+    if dd_engine is not None and dd_engine.startswith("native") and scaling == "strong" and target_cells > args.cells:
+        target = {"cells": target_cells}
+        try:
+            domain.close()
+            del domain, engine
+            torch.cuda.empty_cache()
+            big = pkg.DomainDecomposition.synthetic(target_cells, ndom, rank if world > 1 else None, dev, model,
+                                                    precision=tdtype, skin=args.skin, mixture=args.mixture, pkg=pkg,
+                                                    scaling="strong", dist=dist)
+            k_w, k_t = min(args.warmup, 5), min(args.steps, 20)
+            big.step_(k_w, args.dt, args.rebuild_every)
+            fence()
+            t0 = time.perf_counter()
+            big.step_(k_t, args.dt, args.rebuild_every)
+            fence()
+            dt_big = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([dt_big], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_big = tt.item()
+            ep_b, ek_b, _ = big.totals()
+            nb = big.n_global
+            target.update(atoms=nb, steps=k_t, warmup=k_w, steps_per_sec=k_t / dt_big, ms_per_step=1e3 * dt_big / k_t,
+                          atom_steps_per_sec=nb * k_t / dt_big, rebuilds=big.stats()["rebuilds"],
+                          energy_per_atom={"potential": ep_b / nb, "kinetic": ek_b / nb},
+                          step_roofline_frac=algorithmic_bytes_per_atom_step(w, rc) * nb * k_t / dt_big / 1e9 / world / HBM_PEAK_GBS)
+            ref = os.path.join(ROOT, "profiles", "target_box_1gpu.json")
+            if os.path.exists(ref):
+                with open(ref) as fh:
+                    one = json.load(fh)
+                if one.get("atoms") == nb and one.get("value", 0) > 0:
+                    target["one_gpu_steps_per_sec"] = one["value"]
+                    target["one_gpu_source"] = one.get("source")
+                    target["efficiency_vs_1gpu"] = target["steps_per_sec"] / (world * one["value"])
+            big.close()
+        except Exception as e:                                      # noqa: BLE001
+            target["error"] = repr(e)
+        out["target_box"] = target
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,45 @@
+"""bench.py end to end on the GPU box, at sizes that take seconds: the single-GPU line, and the native decomposition
+(all domains in this process) with the second, larger `target_box` measurement that N > 1 runs carry."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _bench("--cells", "12", "--steps", "10", "--warmup", "4")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["dtype"] == "f64" and d["config"]["atoms"] == 4 * 12 ** 3
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-9)
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert d["energy_per_atom"]["kinetic"] > 0.5
+
+
+def test_native_decomposition_line_and_target_box():
+    d = _bench("--domains", "2", "--cells", "12", "--target-cells", "16", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
+    assert d["config"]["parallelism"] == "dd2x1x1" and d["config"]["decomposition"].startswith("native")
+    assert d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 12 ** 3
+    t = d["target_box"]
+    assert "error" not in t, t
+    assert t["atoms"] == 4 * 16 ** 3 and t["steps_per_sec"] > 0 and t["energy_per_atom"]["kinetic"] > 0.5
+    one = _bench("--cells", "12", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
+    # the decomposed box is the same physical system: same energies per atom after the same number of steps
+    assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
+    assert d["energy_per_atom"]["kinetic"] == pytest.approx(one["energy_per_atom"]["kinetic"], rel=1e-9)
