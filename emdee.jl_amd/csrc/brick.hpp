@@ -486,7 +486,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         return pass;
     };
     auto in_range = [&](const float4 &qi, int p, int c, int tcr) -> bool { return in_range_q(qi, tile[c], p, c, tcr); };
-    if constexpr (ALG == 3) {
+    if constexpr (ALG == 3 || ALG == 5) {
         // ALG 2 with a leaner candidate loop (the build is VALU-issue bound: 2.7 G wave-instructions per rebuild at
         // 10^7 atoms, profiles/r02): the trip count of a tile row is made WAVE-uniform (the longest chunk in the
         // wavefront; a lane whose chunk is shorter tests slots past its chunk and drops those bits afterwards), so
@@ -494,7 +494,10 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         // input of one add (v_cmp -> vcc, v_addc: bits = 2 bits + hit); and the squared distance is accumulated
         // starting from -r_list^2, so "surely inside" and "inside the rounding band" are compares against +-margin.
         static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
-        constexpr int NROWS = 9, NWORDS = (NROWS + 1) / 2;
+        // ALG 3: two 16-bit fields per word (a lane's chunk of a tile row holds <= 16 candidates); ALG 5: one 32-bit field per
+        // word, for long cutoffs / dense boxes (rc = 3.5 sigma: 132 candidates per row, 17 per lane)
+        constexpr int FIELD = ALG == 3 ? BUILD2_FIELD : 32, PER = 32 / FIELD;
+        constexpr int NROWS = 9, NWORDS = (NROWS + PER - 1) / PER;
         constexpr bool BAND = sizeof(real) == 8;              // fp32 boxes: the fp32 test is the definition of the set
 #ifndef EMDEE_BUILD_UNROLL
 #define EMDEE_BUILD_UNROLL 2
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                 const int first = gl * chunk;
                 const int lim = min(chunk, span - first);                           // my candidates; may be <= 0
                 const int cb = c0 + first;
-                cbase[r] = (r & 1) ? cb - BUILD2_FIELD : cb;
+                cbase[r] = cb - (r % PER) * FIELD;
                 const int trips = (wave_group_max<1>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar; the loop is unrolled UNR times
                 unsigned bits = 0;
                 const float4 *cand = tile + cb;
@@ -568,13 +571,13 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     q0 = qn[UNR - 1];
                 }
                 // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
-                bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & ((1u << lim) - 1u)) : 0u;
+                bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & (lim >= 32 ? ~0u : ((1u << lim) - 1u))) : 0u;
                 if (r == 4) {                                                       // the atom itself
                     const int ks = ti - cb;
                     if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
                 }
-                if (r & 1) word[r / 2] |= bits << BUILD2_FIELD;
-                else word[r / 2] = bits;
+                if (r % PER) word[r / PER] |= bits << ((r % PER) * FIELD);
+                else word[r / PER] = bits;
             }
             // ---- phase 2 (as ALG 2): prefix over the lanes of the group, then every lane emits its hits --------
             int mine = 0;
@@ -597,11 +600,11 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
 #pragma unroll
             for (int w = 0; w < NWORDS; w++) {
                 unsigned W = word[w];
-                const int cA = cbase[2 * w], cB = (2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0;
+                const int cA = cbase[PER * w], cB = (PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0;
                 while (W) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
-                    const int c = k + (k >= BUILD2_FIELD ? cB : cA);
+                    const int c = k + ((PER == 2 && k >= FIELD) ? cB : cA);
                     if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
                     e++;
                 }
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     LJModel<real> mdl = a.model;
     LJUni<real> uni = a.uni;
     if (FAST) asm volatile("" : "+v"(uni.nx0), "+v"(uni.idl2), "+v"(uni.p4), "+v"(uni.p3), "+v"(uni.p0));
-    else if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k18));
+    else if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.nx0), "+v"(mdl.idl2), "+v"(mdl.h4), "+v"(mdl.h3), "+v"(mdl.k6));
     else asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
     // SOA kernels index the coordinate planes with the BYTE offsets stored in the list; the others decode the slot
     const unsigned char *plane_b = reinterpret_cast<const unsigned char *>(s_dyn);

@@ -20,6 +20,8 @@ struct LJModel {
     real c60;     // 60 * idl2
     real k3, k6;  // 3 and 6 as kernel arguments: SGPR operands instead of per-iteration literal moves
     real k18, k36;  // 6 x the switch polynomial 1 + 3 x + 6 x^2 (force-only kernels fold W's factor 6 into it)
+    real nx0;       // -x0
+    real h3, h4, h5;  // 6 g = 6 + x^3 (h3 + h4 x + h5 x^2) = 6 - 60 x^3 + 90 x^4 - 36 x^5 (force-only kernels, Horner form)
 };
 
 template <typename real>
@@ -30,6 +32,7 @@ static inline LJModel<real> make_model(const emdee_lj_model &m) {
     r.x0 = r.rs2 * r.idl2;
     r.c60 = (real)60 * r.idl2;
     r.k3 = (real)3; r.k6 = (real)6; r.k18 = (real)18; r.k36 = (real)36;
+    r.nx0 = -r.x0; r.h3 = (real)-60; r.h4 = (real)90; r.h5 = (real)-36;
     return r;
 }
 
@@ -75,6 +78,17 @@ __device__ __forceinline__ void lj_interaction_pair(real r2, real inv_r2, const 
     W_out = W * g + E * mgr;
 }
 
+// x = clamp(a b + c, 0, 1) in one instruction (the VOP3 clamp bit)
+__device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // Force-only launches need neither E nor W on their own, only (W g + E (-r g')) / r2.  Two products fall out of the
 // algebra: the factor 6 of W = 6 (2 b - a) (a = 4 eps s^-6, b = a s^-6) moves into the constants of the switch
 // polynomial, and -r g' / r2 = 60 idl2 x^2 (1-x)^2 needs no r2 at all.  Same function as lj_interaction_pair
@@ -87,12 +101,15 @@ __device__ __forceinline__ real lj_force_over_r2(real r2, real inv_r2, const LJM
     const real b = a * s6;                                             // 4 eps s^-12
     const real d = (real)2 * b - a;                                    // W / 6
     const real em = b - a;                                             // E
-    const real x = switch_clamp(r2 * m.idl2 - m.x0);
+    // x clamped to [0, 1] by the instruction itself; under the caller's test r2 < rc2 only a sum that ROUNDS to exactly
+    // 1.0 differs from the literal clamp (x == 1 -> 0.5, Q2): it yields 0 here, the limit of the function at the cutoff
+    const real x = fma_clamp01(r2, m.idl2, m.nx0);
     const real x2 = x * x;
-    const real u = (real)1 - x;
-    const real u2 = u * u;
-    const real g6 = (u2 * u) * (m.k6 + x * (m.k18 + m.k36 * x));       // 6 g = (1-x)^3 (6 + 18 x + 36 x^2)
-    const real q = m.c60 * (x2 * u2);                                  // -r g' / r2
+    real t = m.h5 * x + m.h4;
+    t = t * x + m.h3;
+    const real g6 = (x2 * x) * t + m.k6;                               // 6 g = 6 - 60 x^3 + 90 x^4 - 36 x^5
+    const real y = x - x2;                                             // x (1 - x)
+    const real q = (m.c60 * y) * y;                                    // -r g' / r2
     return (d * g6) * inv_r2 + em * q;
 }
 
@@ -125,16 +142,6 @@ static inline LJUni<real> make_uni(const LJModel<real> &m, real sigma, real e4) 
     u.c60 = e4 * (real)60 * u.idl2;
     u.inv_sigma = (real)1 / sigma;
     return u;
-}
-__device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
-    float r;
-    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
 }
 template <typename real>
 __device__ __forceinline__ real lj_force_over_r2_uni(real r2, const LJUni<real> &m) {

@@ -397,6 +397,8 @@ struct NbSystem {
                 std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d, own_cap %d, max 3-cell span %d\n", bgrid.nb[0],
                              bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
             build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
+            // crowded tile rows (long cutoffs): the same build with one 32-bit hit field per row
+            if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= 32 * V::GB) build_alg = 5;
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
             row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
@@ -474,6 +476,7 @@ struct NbSystem {
                     if constexpr (V::GB == 8 || V::GB == 16) {
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
                         if (build_alg == 3) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 3, V::G>;
+                        if (build_alg == 5) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 5, V::G>;
                     }
                     lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
                     allow_big_lds(kernel, lds_build_bytes);
