@@ -424,6 +424,15 @@ int32_t emdee_dd_unique_id(uint8_t out[128]) {
         memcpy(out, &id, 128);
     });
 }
+int32_t emdee_dd_describe(const double len[3], const int32_t grid[3], double halo, int32_t rank, int32_t *ndirs,
+                          int32_t dirs[78], int32_t dir_rank[26], double dir_shift[78], int32_t *npeers, int32_t peers[26],
+                          double local_lo[3], double local_len[3], int32_t periodic[3]) {
+    return guarded([&] {
+        EMDEE_REQUIRE(len && grid && ndirs && dirs && dir_rank && dir_shift && npeers && peers && local_lo && local_len && periodic,
+                      EMDEE_ERR_INVALID, "emdee_dd_describe: NULL argument");
+        dd_describe(len, grid, halo, rank, ndirs, dirs, dir_rank, dir_shift, npeers, peers, local_lo, local_len, periodic);
+    });
+}
 int32_t emdee_dd_create(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int32_t rank_first, int32_t n_local,
                         const uint8_t *unique_id, emdee_lj_model model, double skin, int32_t precision, emdee_dd **out) {
     return guarded([&] {

@@ -267,6 +267,13 @@ int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, co
  * the atoms that left their brick + new ghost lists + re-sort + neighbour list.  Trajectories are those of the
  * undivided box to rounding. */
 int32_t emdee_dd_unique_id(uint8_t out[128]);
+/* Host-only (no device needed): the geometry domain `rank` of the grid works with -- its neighbour directions in the
+ * library's fixed order (x fastest; only cut dimensions move), the rank behind each direction and the periodic shift a
+ * ghost sent that way carries, the distinct peer ranks (ascending), and the local box handed to the integrator (brick
+ * plus a halo of width `halo` along cut dimensions, the whole period otherwise).  Arrays sized for 26 directions. */
+int32_t emdee_dd_describe(const double len[3], const int32_t grid[3], double halo, int32_t rank, int32_t *ndirs,
+                          int32_t dirs[78], int32_t dir_rank[26], double dir_shift[78], int32_t *npeers, int32_t peers[26],
+                          double local_lo[3], double local_len[3], int32_t periodic[3]);
 int32_t emdee_dd_create(emdee_ctx *ctx, const double len[3], const int32_t grid[3], int32_t rank_first, int32_t n_local,
                         const uint8_t *unique_id, emdee_lj_model model, double skin, int32_t precision, emdee_dd **out);
 int32_t emdee_dd_destroy(emdee_dd *dd);

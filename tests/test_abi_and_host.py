@@ -137,3 +137,25 @@ def test_julia_shim_ccalls_match_the_header():
             n_calls += 1
     assert n_calls >= 25
 
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
+def test_library_decomposition_geometry_matches_the_host_plan(emdee, world):
+    """emdee_dd_describe (host-only) against domain.DomainPlan, whose conventions the CPU/gloo tests pin: direction
+    order, the rank and periodic shift behind each direction, peers, and the local box handed to the integrator."""
+    E = emdee
+    L, halo = [21.0, 19.0, 23.0], 2.8
+    grid = E.domain.rank_grid(world)
+    for rank in range(world):
+        plan = E.domain.DomainPlan(L, halo, world=world, rank=rank, device="cpu", grid=grid)
+        d = E.dd.describe(L, grid, halo, rank)
+        assert d["dirs"] == [tuple(s) for s in plan.dirs]
+        assert d["dir_rank"] == plan.dir_rank
+        assert d["dir_shift"] == plan.dir_shift
+        assert d["peers"] == sorted(set(plan.dir_rank))
+        assert d["local_lo"] == pytest.approx(plan.local_lo, abs=1e-15) and d["local_len"] == pytest.approx(plan.local_len, abs=1e-15)
+        assert d["periodic"] == plan.periodic
+    with pytest.raises(E.EmDeeError):
+        E.dd.describe(L, (4, 1, 1), halo, 0)                    # more than 3 bricks per dimension
+    with pytest.raises(E.EmDeeError):
+        E.dd.describe([5.0, 19.0, 23.0], (2, 1, 1), halo, 0)    # halo wider than a brick
