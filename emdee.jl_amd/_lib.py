@@ -85,6 +85,7 @@ SIGNATURES = {
     "emdee_md_set_langevin_ids": [_p, _p],
     "emdee_md_langevin_normals": [_p, C.c_uint64, C.c_uint64, _p, _i32, _p],
     "emdee_dd_unique_id": [_p],
+    "emdee_dd_rccl_selftest": [_p, _i32],
     "emdee_dd_describe": [_d3, _i3, _dbl, _i32, C.POINTER(_i32), _p, _p, _p, C.POINTER(_i32), _p, _d3, _d3, _i3],
     "emdee_dd_create": [_p, _d3, _i3, _i32, _i32, _p, LJModelC, _dbl, _i32, _pp],
     "emdee_dd_destroy": [_p],

@@ -424,6 +424,9 @@ int32_t emdee_dd_unique_id(uint8_t out[128]) {
         memcpy(out, &id, 128);
     });
 }
+int32_t emdee_dd_rccl_selftest(emdee_ctx *ctx, int32_t n_bytes) {
+    return guarded([&] { REQUIRE_PTR(ctx, "ctx"); dd_rccl_selftest(ctx, n_bytes); });
+}
 int32_t emdee_dd_describe(const double len[3], const int32_t grid[3], double halo, int32_t rank, int32_t *ndirs,
                           int32_t dirs[78], int32_t dir_rank[26], double dir_shift[78], int32_t *npeers, int32_t peers[26],
                           double local_lo[3], double local_len[3], int32_t periodic[3]) {

@@ -65,6 +65,7 @@ struct IDd {
     virtual void stats(int64_t out[4]) = 0;
 };
 
+void dd_rccl_selftest(emdee_ctx *ctx, int n_bytes);
 // host-only description of one domain's geometry (dd.hpp: DdGeom), for emdee_dd_describe
 void dd_describe(const double len[3], const int32_t grid[3], double halo, int rank, int32_t *ndirs, int32_t *dirs,
                  int32_t *dir_rank, double *dir_shift, int32_t *npeers, int32_t *peers, double *local_lo, double *local_len,

@@ -267,6 +267,10 @@ int32_t emdee_md_langevin_normals(emdee_md *md, uint64_t seed, uint64_t step, co
  * the atoms that left their brick + new ghost lists + re-sort + neighbour list.  Trajectories are those of the
  * undivided box to rounding. */
 int32_t emdee_dd_unique_id(uint8_t out[128]);
+/* Diagnostic: resolve librccl, build a ONE-rank communicator on the context's device and push n_bytes through
+ * ncclSend/ncclRecv to itself (one group, a stream of its own) and 3 doubles through ncclAllReduce; fails unless the
+ * bytes arrive unchanged.  Exercises the run-time binding (symbols, enum values, ncclUniqueId by value) on a one-GPU box. */
+int32_t emdee_dd_rccl_selftest(emdee_ctx *ctx, int32_t n_bytes);
 /* Host-only (no device needed): the geometry domain `rank` of the grid works with -- its neighbour directions in the
  * library's fixed order (x fastest; only cut dimensions move), the rank behind each direction and the periodic shift a
  * ghost sent that way carries, the distinct peer ranks (ascending), and the local box handed to the integrator (brick

@@ -176,3 +176,15 @@ def test_dd_box_with_interior_bricks(emdee, world):
     e_dd, e_md = dd.totals(), md.totals()
     assert e_dd[0] == pytest.approx(e_md[0], rel=1e-10) and e_dd[1] == pytest.approx(e_md[1], rel=1e-10)
     assert dd.stats()["rebuilds"] >= 3
+
+
+def test_rccl_binding_on_one_rank(emdee):
+    """The RCCL transport cannot run between two ranks on a one-GPU box; what can be checked here is the run-time
+    binding it rests on: librccl resolved with dlopen, ncclGetUniqueId / ncclCommInitRank (the 128-byte id by value),
+    ncclSend + ncclRecv in one group on a stream of their own, ncclAllReduce, the enum values taken from rccl.h."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    emdee.dd.rccl_selftest(torch.device("cuda", 0), 1 << 20)
+    emdee.dd.rccl_selftest(torch.device("cuda", 0), 16)
+    uid = emdee.DomainDecomposition.unique_id()
+    assert len(uid) == 128 and any(uid)
