@@ -417,13 +417,13 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
     // own-atom table entries first (their global loads fly while the tile is being staged)
-    int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS];
+    int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS], own_oc[OWN_REGS];
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        own_p[k] = own_ti[k] = 0; own_key[k] = 0;
+        own_p[k] = own_ti[k] = 0; own_key[k] = 0; own_oc[k] = 0;
         if (o < n_own) {
-            brick_locate(T, o, own_ti[k], own_p[k]);
+            own_oc[k] = brick_locate(T, o, own_ti[k], own_p[k]);
             own_key[k] = a.perm[own_p[k]];
         }
     }
@@ -441,12 +441,12 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
+        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], (own_oc[k] << 20) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
-        brick_locate(T, o, ti, p);
-        T.oinfo[o] = make_int2(p, ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+        const int oc = brick_locate(T, o, ti, p);
+        T.oinfo[o] = make_int2(p, (oc << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
     __syncthreads();
 
@@ -508,9 +508,10 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
             const int o = ob + gid;
             const bool have = o < n_own;
-            int ti = 0, p = 0, oc = 0;
-            if (have) oc = brick_locate(T, o, ti, p);
-            const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+            // own atom: cell-order slot, tile slot, own cell and "owned" flag, located once while the tile was staged
+            const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
+            const int ti = info.y & 0xffff, p = info.x, oc = info.y >> 20;
+            const bool act = have && ((info.y >> 16) & 1) != 0;   // ghosts own no row
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const float4 qi = tile[ti];
             unsigned short *row = a.nbr + (size_t)p * a.stride;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
             const bool have = o < n_own;
             int ti = 0, p = 0, oc = 0;
             if (have) oc = brick_locate(T, o, ti, p);
-            const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+            const bool act = have && ((T.oinfo[o].y >> 16) & 1) != 0;   // ghosts own no row
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const float4 qi = tile[ti];
             unsigned short *row = a.nbr + (size_t)p * a.stride;
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         const bool have = o < n_own;
         int ti = 0, p = 0, oc = 0;
         if (have) oc = brick_locate(T, o, ti, p);
-        const bool act = have && (T.oinfo[o].y >> 16) != 0;   // ghosts own no row
+        const bool act = have && ((T.oinfo[o].y >> 16) & 1) != 0;   // ghosts own no row
         const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
         const float4 qi = tile[ti];
         unsigned short *row = a.nbr + (size_t)p * a.stride;
@@ -1020,7 +1021,9 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     }
                     const real cm = a.kick_c * imv;
                     vx += cm * fx; vy += cm * fy; vz += cm * fz;
-                    if (a.noise) { vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz; }
+                    // Langevin O step; NVE launches pass c1 = 1 and the noise registers stay 0: v 1 + 0 is v, bit for bit,
+                    // and the three fmas cost less than the selects an `if (a.noise)` is compiled into
+                    vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz;
                     a.vel_next[p] = vx; a.vel_next[a.pitch + p] = vy; a.vel_next[2 * a.pitch + p] = vz;
                     Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
                     if (FAST) { r.x += a.dt * vx; r.y += a.dt * vy; r.z += a.dt * vz; }   // (the tile holds scaled coordinates)

@@ -306,7 +306,7 @@ struct NbSystem {
         a.guard = step_guard;
         a.btab = btab_valid ? btab.ptr : nullptr;
         a.user_f = out_f; a.user_e = out_e; a.user_w = out_w;
-        a.noise = lgv_on ? noise.ptr : nullptr; a.lgv_c1 = (real)lgv_c1;
+        a.noise = lgv_on ? noise.ptr : nullptr; a.lgv_c1 = lgv_on ? (real)lgv_c1 : (real)1;
         return a;
     }
 
