@@ -236,7 +236,7 @@ struct DdImpl : IDd {
     RcclApi::Comm comm = nullptr;
     bool loaded = false;
     int64_t n_global = 0;
-    int max_batch = 4;
+    int max_batch = DD_MAX_BATCH;
     bool overlap = true;
     int last_interval = 0;
     // Langevin
@@ -683,6 +683,9 @@ struct DdImpl : IDd {
             // ---- a batch of inner steps: force + full kick + drift in one kernel pass each
             int B = std::min(max_batch, nsteps - s);
             if (rebuild_every > 0) B = std::min(B, std::max(1, rebuild_every - dom[0]->since_build - 1));
+            // displacement trigger: queue what the previous interval between rebuilds says is safe, then one step at a
+            // time until the request comes -- a cancelled step costs a halo exchange that nobody uses
+            else B = std::max(1, std::min(B, last_interval > 0 ? last_interval - dom[0]->since_build - 1 : 2));
             if (!tiled) B = 1;
             if (rebuild_every > 0 && dom[0]->since_build + 1 >= rebuild_every) {
                 // fixed cadence: rebuild at the current positions, then the un-fused equivalent of one inner step
@@ -738,8 +741,8 @@ struct DdImpl : IDd {
             if (ran < B) {
                 // the positions of step s were flagged: rebuild there (evaluates the forces), then the un-fused
                 // equivalent of that inner step
+                last_interval = dom[0]->since_build;          // steps the list just retired has served
                 redistribute(true);
-                last_interval = 0;
                 if (s < nsteps) {
                     for (auto &pd : dom) {
                         EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
