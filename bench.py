@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--dd", choices=["native", "torch"], default="native",
                     help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
                          "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
+    ap.add_argument("--launch-timeout", type=int, default=900, help="self-launched N > 1 runs: seconds before the ranks are stopped")
     ap.add_argument("--domains", type=int, default=0,
                     help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
                          "process on cuda:0 (device-to-device halo copies instead of RCCL)")
@@ -88,19 +89,39 @@ def parse_args():
 
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this process has not
-    imported torch or touched the GPU; it only relays the child's output and exit code)."""
+    imported torch or touched the GPU; it only relays the child's output and exit code).  If the native decomposition
+    run fails or exceeds --launch-timeout, the ranks are started once more on the torch.distributed driver."""
+    import signal
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+
+    def run(extra):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        child = subprocess.Popen(cmd, env=env, start_new_session=True)         # its own process group: killable as a whole
+        try:
+            return child.wait(timeout=args.launch_timeout)
+        except subprocess.TimeoutExpired:
+            print("bench.py: the %d-rank run exceeded %d s and is being stopped" % (args.gpus, args.launch_timeout), file=sys.stderr)
+            try:
+                os.killpg(child.pid, signal.SIGKILL)                             # exactly the group started above
+            except ProcessLookupError:
+                pass
+            child.wait()
+            return 124
+
+    rc = run([])
+    if rc != 0 and args.dd == "native":
+        print("bench.py: native decomposition run ended with status %d; once more with --dd torch" % rc, file=sys.stderr)
+        rc = run(["--dd", "torch"])
+    return rc
 
 
 def make_box(pkg, cells, mixture):
