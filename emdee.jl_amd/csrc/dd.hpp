@@ -322,13 +322,6 @@ struct DdImpl : IDd {
         EMDEE_REQUIRE(l >= 0 && l < n_local, EMDEE_ERR_INVALID, "emdee_dd: local domain %d out of range [0, %d)", l, n_local);
         return *dom[l];
     }
-    void sync_all() {
-        for (auto &d : dom) {
-            EMDEE_HIP_CHECK(hipStreamSynchronize(d->comm));
-            EMDEE_HIP_CHECK(hipStreamSynchronize(d->stream()));
-        }
-    }
-
     // ---------------------------------------------------------------- transports
     // Every local domain has filled its Xfer and recorded ev_packed on its compute stream once the send buffer is
     // complete.  Afterwards ev_done (communication stream) marks the arrival of all its messages.
