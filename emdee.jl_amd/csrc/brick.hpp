@@ -41,6 +41,9 @@ namespace emdee {
 enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2, BRICK_STEP = 3 };
 
 constexpr int EPL = 8;   // neighbour entries per lane per 16-byte load
+// entries the force kernels read of every row without looking at its length: the NPF prefetched blocks of 8 G entries
+// and the one after them (rows are sentinel-padded, so the row stride must hold them)
+constexpr int brick_min_stride(int G) { return (((EPL * G) >= 128 ? 1 : 2) + 1) * EPL * G; }
 
 template <int BX_, int BY_, int BZ_>
 struct BrickShape {
@@ -845,16 +848,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // block after them is requested when the atom's turn starts and arrives while those 64 are being worked on).
     constexpr int NPF = (BLK >= 128) ? 1 : 2;   // (G = 4: 64 entries ahead, the rest of the row one block ahead)
     struct IdxBuf { uint4 q[NPF]; };
+    // (a group past the brick's last atom reads the last atom's row: valid memory, no zero-fill and no branch; its own
+    // position is the sentinel record, so nothing it reads passes the cutoff test, and nothing it computes is stored)
     auto fetch = [&](int o) {
         IdxBuf b;
+        const unsigned short *row = a.nbr + (size_t)T.oinfo[min(o, n_own - 1)].x * a.stride + gl * EPL;
 #pragma unroll
-        for (int k = 0; k < NPF; k++) b.q[k] = make_uint4(0, 0, 0, 0);
-        if (o < n_own) {
-            const unsigned short *row = a.nbr + (size_t)T.oinfo[o].x * a.stride + gl * EPL;
-#pragma unroll
-            for (int k = 0; k < NPF; k++)
-                if (k * BLK < a.stride) b.q[k] = *reinterpret_cast<const uint4 *>(row + k * BLK);
-        }
+        for (int k = 0; k < NPF; k++) b.q[k] = *reinterpret_cast<const uint4 *>(row + k * BLK);   // stride >= (NPF + 1) BLK (host)
         return b;
     };
     IdxBuf nxt = fetch(gid);
@@ -866,8 +866,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         const IdxBuf cur = nxt;
         // rows longer than the prefetched blocks (rc = 3.5 sigma: 184 entries): the next block is requested
         // now and arrives while the first NPF blocks are being worked on
-        uint4 more = make_uint4(0, 0, 0, 0);
-        if (NPF * BLK < m) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + NPF * BLK + gl * EPL);
+        // (rows are sentinel-padded up to the stride, and the stride holds at least NPF + 1 blocks: read whatever the row length)
+        uint4 more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + NPF * BLK + gl * EPL);
         nxt = fetch(o + NGROUPS);
         const int wm = wave_group_max<G>(m);
         real xi, yi, zi, hs_i, te_i;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         for (int b0 = NPF * BLK; b0 < wm; b0 += BLK) {        // longer rows: one block ahead
             const uint4 q = more;
             more = make_uint4(0, 0, 0, 0);
-            if (b0 + BLK < m) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + BLK + gl * EPL);
+            if (b0 + BLK < a.stride) more = *reinterpret_cast<const uint4 *>(a.nbr + (size_t)p * a.stride + b0 + BLK + gl * EPL);
             block(q, b0);
         }
         if (PACKED) {

@@ -446,7 +446,10 @@ struct NbSystem {
             variant = 8;
             if (!plan_bricks()) { variant = 0; plan_bricks(); }
         }
-        if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
+        if (brick_active) {
+            stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
+            with_brick_variant(variant, [&](auto v) { stride = std::max(stride, brick_min_stride(decltype(v)::G)); });
+        }
         // the build kernel's LDS (fp32 tile + tables + one row buffer per lane group) must fit as well: very dense or
         // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
         if (brick_active && !build_fits_lds()) brick_active = false;
