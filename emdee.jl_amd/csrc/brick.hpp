@@ -532,7 +532,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                 const int lim = min(chunk, span - first);                           // my candidates; may be <= 0
                 const int cb = c0 + first;
                 cbase[r] = cb - (r % PER) * FIELD;
-                const int trips = (wave_group_max<1>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar; the loop is unrolled UNR times
+                const int trips = (wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar (chunk is the same in all lanes of a group); unrolled UNR times
                 unsigned bits = 0;
                 const float4 *cand = tile + cb;
                 // one test: the hit bit of candidate q (slot index c, chunk position k) is shifted into `bits`
@@ -600,22 +600,34 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     incl += gl >= 8 ? t : 0;
                 }
             }
+            // Hits go to the row buffer in PLAIN order (hit number e at rowbuf[e]: one shifted add and one 2-byte LDS store
+            // per hit); the lane-major block layout the force kernels read (row_position) is produced while the row is
+            // flushed, each 16-byte output chunk gathering its 8 entries.  A row that overflows the stride keeps
+            // overwriting its last slot: the host sees the count, grows the stride and builds again.
             unsigned e = (unsigned)(incl - mine);
+            const unsigned last = ustride - 1u;
 #pragma unroll
             for (int w = 0; w < NWORDS; w++) {
                 unsigned W = word[w];
-                const int cA = cbase[PER * w], cB = (PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0;
+                const int cA = cbase[PER * w] << a.idx_shift, cB = ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0) << a.idx_shift;
                 while (W) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
-                    const int c = k + ((PER == 2 && k >= FIELD) ? cB : cA);
-                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
+                    rowbuf[min(e, last)] = (unsigned short)((k << a.idx_shift) + ((PER == 2 && k >= FIELD) ? cB : cA));
                     e++;
                 }
             }
             if (have) {
-                for (int c = gl * EPL; c < a.stride; c += G * EPL)
-                    *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
+                constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
+                for (int c = gl * EPL; c < a.stride; c += G * EPL) {
+                    const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7
+                    uint4 q;
+                    q.x = (unsigned)src[0 * GL] | ((unsigned)src[1 * GL] << 16);
+                    q.y = (unsigned)src[2 * GL] | ((unsigned)src[3 * GL] << 16);
+                    q.z = (unsigned)src[4 * GL] | ((unsigned)src[5 * GL] << 16);
+                    q.w = (unsigned)src[6 * GL] | ((unsigned)src[7 * GL] << 16);
+                    *reinterpret_cast<uint4 *>(row + c) = q;
+                }
                 if (gl == G - 1) {                            // the last lane's inclusive prefix is the row length
                     a.cnt[p] = act ? (int)min((unsigned)incl, ustride) : 0;
                     if ((unsigned)incl > ustride) atomicMax(&a.flags[0], incl);
