@@ -188,3 +188,27 @@ def test_rccl_binding_on_one_rank(emdee):
     emdee.dd.rccl_selftest(torch.device("cuda", 0), 16)
     uid = emdee.DomainDecomposition.unique_id()
     assert len(uid) == 128 and any(uid)
+
+
+def test_dd_binary_mixture_long_cutoff(emdee, oracle):
+    """BASELINE configs[4] in miniature, decomposed: two species (Lorentz-Berthelot through the LJAtom encoding), rc = 3.5
+    sigma (halo 3.8 of a 6.84-wide brick, long neighbour rows, the general-species kernels in both phases) on 8 domains."""
+    E = emdee
+    rc, rs = 3.5, 3.0
+    pos, vel, eps, sigma, L = _global_box(E.synthetic)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dev = torch.device("cuda", 0)
+    dd = E.DomainDecomposition([L] * 3, (2, 2, 2), E.LennardJonesModel(rc, rs), skin=SKIN, device=dev)
+    for r in range(8):
+        mine = np.arange(r, N, 8)
+        dd.set_atoms_(r, E.cu(pos[mine], dev), E.cu(vel[mine], dev), E.cu(atoms[mine], dev), torch.from_numpy(mine).to(dev))
+    dd.load_()
+    dd.step_(20, DT, 0)
+    ref = oracle.verlet(pos, vel, L, oracle.model(rc, rs), oracle.lj_atoms(eps, sigma), DT, 20)
+    x, v, f = _gather(dd, 8, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(f - ref["f"]).max() < 1e-6 * np.abs(ref["f"]).max()
+    e1 = dd.totals()
+    assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
