@@ -535,44 +535,51 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                 const int trips = (wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar (chunk is the same in all lanes of a group); unrolled UNR times
                 unsigned bits = 0;
                 const float4 *cand = tile + cb;
-                // one test: the hit bit of candidate q (slot index c, chunk position k) is shifted into `bits`
-                auto test = [&](const float4 &q, int k) {
+                // d^2 - r_list^2 of candidate q, accumulated from -r_list^2
+                auto dist = [&](const float4 &q) {
                     const float dx = qi.x - q.x, dyy = qi.y - q.y, dzz = qi.z - q.z;
-                    float t = __builtin_fmaf(dx, dx, nrl2);                         // d^2 - r_list^2
+                    float t = __builtin_fmaf(dx, dx, nrl2);
                     t = __builtin_fmaf(dyy, dyy, t);
-                    t = __builtin_fmaf(dzz, dzz, t);
-                    if constexpr (BAND) {
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabsf(t) <= margin_v) != 0, 0)) {
-                            // rounding band: decided with the exact fp64 records, for the lanes concerned (and only for
-                            // slots of the lane's own chunk: what lies past it is dropped below and may not be a record)
-                            if (__builtin_fabsf(t) <= margin_v && k < lim) {
-                                const int c = cb + k;
-                                const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
-                                const int sh = T.shift[tc];
-                                const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(q.w)];
-                                const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
-                                const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
-                                const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
-                                t = (ex * ex + ey * ey + ez * ez < a.rlist2) ? -1.f : 1.f;
-                            }
-                        }
+                    return __builtin_fmaf(dzz, dzz, t);
+                };
+                // rounding band (fp64 boxes): decided with the exact fp64 records, for the lanes concerned -- and only for
+                // slots of the lane's own chunk: what lies past it is dropped below and may not be a record
+                auto exact = [&](float &t, const float4 &q, int k) {
+                    if (__builtin_fabsf(t) <= margin_v && k < lim) {
+                        const int c = cb + k;
+                        const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
+                        const int sh = T.shift[tc];
+                        const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(q.w)];
+                        const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
+                        const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
+                        const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
+                        t = (ex * ex + ey * ey + ez * ez < a.rlist2) ? -1.f : 1.f;
                     }
-                    // (keeps the whole 16-byte record alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
-                    if constexpr (!BAND) asm volatile("" : : "v"(q.w));
-                    // fp32 boxes (margin 0): the sign of this fused sum IS the definition of the listed set
+                };
+                // the hit bit enters through the carry: bits = 2 bits + (t < -margin)
+                // (fp32 boxes, margin 0: the sign of the fused sum IS the definition of the listed set)
+                auto shift_in = [&](float t) {
                     asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
                                  : "+v"(bits) : "v"(t), "v"(nmargin_v) : "vcc");
                 };
-                float4 q0 = cand[0];                                                // candidates in flight: UNR + 1
+                static_assert(UNR == 2, "the candidate loop takes two candidates per trip");
+                // Two candidates per trip, loaded at its top: with six wavefronts per SIMD the LDS latency hides behind the
+                // other waves' arithmetic, and nothing is carried from trip to trip (no register rotation).  The band test
+                // of the pair is one compare of min(|t0|, |t1|) with the margin.
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int k = 0; k < trips; k += UNR) {                              // (reads past the chunk / the tile: harmless)
-                    float4 qn[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; u++) qn[u] = cand[k + 1 + u];
-                    test(q0, k);
-#pragma unroll
-                    for (int u = 0; u + 1 < UNR; u++) test(qn[u], k + 1 + u);
-                    q0 = qn[UNR - 1];
+                for (int k = 0; k < trips; k += 2) {                                // (reads past the chunk / the tile: harmless)
+                    const float4 qa = cand[k], qb = cand[k + 1];
+                    // (keeps the whole 16-byte records alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
+                    if constexpr (!BAND) asm volatile("" : : "v"(qa.w), "v"(qb.w));
+                    float t0 = dist(qa), t1 = dist(qb);
+                    if constexpr (BAND) {
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fabsf(t0), __builtin_fabsf(t1)) <= margin_v) != 0, 0)) {
+                            exact(t0, qa, k);
+                            exact(t1, qb, k + 1);
+                        }
+                    }
+                    shift_in(t0);
+                    shift_in(t1);
                 }
                 // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
                 bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & (lim >= 32 ? ~0u : ((1u << lim) - 1u))) : 0u;
