@@ -562,24 +562,33 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
                                  : "+v"(bits) : "v"(t), "v"(nmargin_v) : "vcc");
                 };
-                static_assert(UNR == 2, "the candidate loop takes two candidates per trip");
-                // Two candidates per trip, loaded at its top: with six wavefronts per SIMD the LDS latency hides behind the
+                // UNR candidates per trip, loaded at its top: with six wavefronts per SIMD the LDS latency hides behind the
                 // other waves' arithmetic, and nothing is carried from trip to trip (no register rotation).  The band test
-                // of the pair is one compare of min(|t0|, |t1|) with the margin.
+                // of the group is one compare of the smallest |t| with the margin.
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int k = 0; k < trips; k += 2) {                                // (reads past the chunk / the tile: harmless)
-                    const float4 qa = cand[k], qb = cand[k + 1];
+                for (int k = 0; k < trips; k += UNR) {                              // (reads past the chunk / the tile: harmless)
+                    float4 q[UNR];
+                    float t[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) q[u] = cand[k + u];
                     // (keeps the whole 16-byte records alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
-                    if constexpr (!BAND) asm volatile("" : : "v"(qa.w), "v"(qb.w));
-                    float t0 = dist(qa), t1 = dist(qb);
+                    if constexpr (!BAND) {
+#pragma unroll
+                        for (int u = 0; u < UNR; u++) asm volatile("" : : "v"(q[u].w));
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) t[u] = dist(q[u]);
                     if constexpr (BAND) {
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fabsf(t0), __builtin_fabsf(t1)) <= margin_v) != 0, 0)) {
-                            exact(t0, qa, k);
-                            exact(t1, qb, k + 1);
+                        float tm = __builtin_fabsf(t[0]);
+#pragma unroll
+                        for (int u = 1; u < UNR; u++) tm = __builtin_fminf(tm, __builtin_fabsf(t[u]));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tm <= margin_v) != 0, 0)) {
+#pragma unroll
+                            for (int u = 0; u < UNR; u++) exact(t[u], q[u], k + u);
                         }
                     }
-                    shift_in(t0);
-                    shift_in(t1);
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) shift_in(t[u]);
                 }
                 // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
                 bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & (lim >= 32 ? ~0u : ((1u << lim) - 1u))) : 0u;
