@@ -361,7 +361,7 @@ def main():
         "energy_per_atom": {"potential": ep / N_energy, "kinetic": ek / N_energy},
     }
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, args)
         cp = cache_path(args)
         if world == 1 and domain is None:
