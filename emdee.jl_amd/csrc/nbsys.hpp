@@ -580,11 +580,12 @@ struct NbSystem {
     // raises *trigger when an atom it moved is now skin/2 away from its position at the last build (default: flags[1]).
     // carry_ghosts: copy the ghosts' current coordinates into the buffer that becomes current (callers that unpack
     // fresh ghosts before every force evaluation, as emdee_dd_step does, do not need it).
+    // noise_ready: the caller has already queued prepare_noise(dt) for this step (it must precede work on another stream).
     bool fused_step(double c, double dt, int phase = 0, const int *guard = nullptr, int *trigger = nullptr,
-                    bool carry_ghosts = true) {
+                    bool carry_ghosts = true, bool noise_ready = false) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         if (!brick_active || n_total == 0) return false;
-        if (phase != 2) prepare_noise(dt);                   // phases 1 and 2 are the two halves of one step
+        if (phase != 2 && !noise_ready) prepare_noise(dt);   // phases 1 and 2 are the two halves of one step
         {
             Timed t(this, T_STEP);
             step_c = c; step_dt = dt;
