@@ -413,7 +413,9 @@ struct DdImpl : IDd {
     // collective: hand every atom to the brick that contains it, choose and exchange the ghosts, load the engines
     void load() override {
         use_device(user_ctx);
+        for (auto &d : dom) d->sys().uniform_known = -1;
         redistribute(false);
+        agree_on_species();
         if (n_global == 0) {
             std::vector<std::vector<double>> v;
             for (auto &d : dom) v.push_back({(double)d->n_owned});
@@ -426,12 +428,36 @@ struct DdImpl : IDd {
 
     // stable partition of items 0..n-1 by mask bits into nbins bins: counts and scanned offsets (device), starts and
     // per-peer counts into small[0..] / small[33..]
-    void partition_count(Domain<real> &d, int n, int nbins, const DdBins &pb) {
+    // One species everywhere, or not?  Every engine looked at its own atoms (owned + ghosts) during the load; agree once
+    // over all domains, so that later loads -- atoms only change owner -- skip that scan and its read-back.
+    void agree_on_species() {
+        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (double)u; };
+        std::vector<std::vector<double>> v;
+        for (auto &d : dom)
+            v.push_back({d->sys().uniform_atoms ? 1.0 : 0.0, bits(d->sys().uni_first.half_sigma), bits(d->sys().uni_first.twice_sqrt_eps)});
+        double sum[3];
+        allreduce_sum(v, 3, sum);
+        std::vector<std::vector<double>> ok;
+        for (auto &d : dom) {
+            const bool same = sum[0] == (double)world && sum[1] == world * bits(d->sys().uni_first.half_sigma) &&
+                              sum[2] == world * bits(d->sys().uni_first.twice_sqrt_eps);
+            ok.push_back({same ? 1.0 : 0.0});
+        }
+        double agreed = 0;
+        allreduce_sum(ok, 1, &agreed);
+        for (auto &d : dom) d->sys().uniform_known = agreed == (double)world ? 1 : 0;
+    }
+
+    // stable partition of items 0..n-1 by mask bits into nbins bins.  partition_prepare sizes and clears the per-block
+    // counts, the kernel that produces the masks fills them (part_count_block), partition_finish scans them and leaves the
+    // bin starts in small[0..] and the per-peer counts in small[33..]
+    int partition_prepare(Domain<real> &d, int n, int nbins) {
         const int nblocks = std::max(1, (int)blocks_for(n, PART_BLOCK));
         d.counts.ensure((size_t)nbins * nblocks + 2);
         EMDEE_HIP_CHECK(hipMemsetAsync(d.counts.ptr, 0, ((size_t)nbins * nblocks + 1) * sizeof(int), d.stream()));
-        if (n > 0)
-            hipLaunchKernelGGL(k_part_count, dim3(nblocks), dim3(PART_BLOCK), 0, d.stream(), n, d.mask.ptr, nbins, nblocks, d.counts.ptr);
+        return nblocks;
+    }
+    void partition_finish(Domain<real> &d, int nbins, int nblocks, const DdBins &pb) {
         d.scanner.run(d.counts.ptr, (size_t)nbins * nblocks + 1, d.stream());
         hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, d.stream(), nbins, nblocks, d.counts.ptr, d.small.ptr, pb, d.small.ptr + 33);
     }
@@ -489,13 +515,14 @@ struct DdImpl : IDd {
             d.mask.ensure((size_t)d.n_owned + 1);
             EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
             // ---- 1. owner of every atom; partition into stay | one bin per peer
+            const int nb1 = 1 + d.geo.npeers, nblk1 = partition_prepare(d, d.n_owned, nb1);
             if (d.n_owned > 0)
-                hipLaunchKernelGGL((k_dd_classify<real>), dim3(blocks_for(d.n_owned, 256)), dim3(256), 0, d.stream(), d.n_owned,
-                                   d.x.ptr, d.geo.template device<real>(), d.mask.ptr, d.small.ptr + 95);
+                hipLaunchKernelGGL((k_dd_classify<real>), dim3(nblk1), dim3(PART_BLOCK), 0, d.stream(), d.n_owned, d.x.ptr,
+                                   d.geo.template device<real>(), d.mask.ptr, d.small.ptr + 95, nb1, nblk1, d.counts.ptr);
             DdBins pb{};
             pb.npeers = d.geo.npeers;
             for (int p = 0; p <= d.geo.npeers + 1; p++) pb.lo[p] = std::min(1 + p, 1 + d.geo.npeers);
-            partition_count(d, d.n_owned, 1 + d.geo.npeers, pb);
+            partition_finish(d, nb1, nblk1, pb);
         }
         exchange_counts_and_read();
         // ---- 2. move the leavers
@@ -532,13 +559,15 @@ struct DdImpl : IDd {
             // ---- 3. ghosts: which neighbours need which of my atoms
             d.mask.ensure((size_t)n_new + 1);
             EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
-            if (n_new > 0 && d.geo.ghost_nbins > 0)
-                hipLaunchKernelGGL((k_dd_ghost_mask<real>), dim3(blocks_for(n_new, 256)), dim3(256), 0, d.stream(), n_new, d.x.ptr,
-                                   d.geo.template device<real>(), d.mask.ptr);
+            const int n_sel = d.geo.ghost_nbins > 0 ? n_new : 0, nb2 = std::max(1, d.geo.ghost_nbins);
+            const int nblk2 = partition_prepare(d, n_sel, nb2);
+            if (n_sel > 0)
+                hipLaunchKernelGGL((k_dd_ghost_mask<real>), dim3(nblk2), dim3(PART_BLOCK), 0, d.stream(), n_sel, d.x.ptr,
+                                   d.geo.template device<real>(), d.mask.ptr, nb2, nblk2, d.counts.ptr);
             DdBins pb{};
             pb.npeers = d.geo.npeers;
             for (int p = 0; p <= d.geo.npeers + 1; p++) pb.lo[p] = d.geo.peer_bin_lo[std::min(p, d.geo.npeers)];
-            partition_count(d, d.geo.ghost_nbins > 0 ? n_new : 0, std::max(1, d.geo.ghost_nbins), pb);
+            partition_finish(d, nb2, nblk2, pb);
         }
         exchange_counts_and_read();
         for (auto &pd : dom) {

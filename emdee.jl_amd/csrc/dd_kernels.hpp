@@ -56,66 +56,18 @@ struct DdPlan {
 static inline size_t dd_msg_begin(const int *start, int p, size_t w) { return (size_t)p * DD_HDR + (size_t)start[p] * 3 * w; }
 static inline size_t dd_msg_bytes(const int *start, int p, size_t w) { return DD_HDR + (size_t)(start[p + 1] - start[p]) * 3 * w; }
 
-// ------------------------------------------------------------------------------------ ownership
-// Wrap every owned atom into the global box and name the rank whose brick contains it.
-// mask[i] = 1 << bin: bin 0 = stays here, 1 + p = leaves for peer p.  An atom that would have to
-// jump over a brick (cannot happen while the halo exceeds the displacement between rebuilds) raises *err.
-template <typename real>
-__global__ void k_dd_classify(int n, real *__restrict__ x, DdDev<real> g, unsigned *__restrict__ mask, int *__restrict__ err) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        real p = x[3 * (size_t)i + d];
-        p -= g.L[d] * floor(p / g.L[d]);
-        x[3 * (size_t)i + d] = p;
-        c[d] = min(max((int)floor(p / g.width[d]), 0), g.grid[d] - 1);
-    }
-    const int dest = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
-    int bin = g.rank_bin[dest];
-    if (bin < 0) { *err = 1; bin = 0; }
-    mask[i] = 1u << bin;
-}
-
-// Which neighbours need this owned atom as a ghost: bit dir_bin[k] for every direction k whose halo holds it.
-template <typename real>
-__global__ void k_dd_ghost_mask(int n, const real *__restrict__ x, DdDev<real> g, unsigned *__restrict__ mask) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    bool near_lo[3], near_hi[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        const real p = x[3 * (size_t)i + d];
-        near_lo[d] = g.cut[d] && p < g.lo[d] + g.halo;
-        near_hi[d] = g.cut[d] && p >= g.hi[d] - g.halo;
-    }
-    unsigned m = 0;
-    for (int k = 0; k < g.ndirs; k++) {
-        bool in = true;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const int s = g.dir[k][d];
-            in = in && (s == 0 || (s > 0 ? near_hi[d] : near_lo[d]));
-        }
-        if (in) m |= 1u << g.dir_bin[k];
-    }
-    mask[i] = m;
-}
-
 // ------------------------------------------------------------------------------------ stable multi-bin partition
 // Items carry a bit mask of bins (<= 32 bins; an item may sit in several: a corner atom is a ghost of up to
 // seven neighbours).  Output: for every bin, the ids of its items in ascending order -- deterministic, no
-// atomics on the output.  count -> exclusive scan of counts[bin][block] -> scatter.
+// atomics on the output.  count -> exclusive scan of counts[bin][block] -> scatter.  The kernels that produce the
+// masks (ownership, ghost selection) count their block themselves: blocks of PART_BLOCK items.
 constexpr int PART_BLOCK = 256;
 
-static __global__ __launch_bounds__(PART_BLOCK) void k_part_count(int n, const unsigned *__restrict__ mask, int nbins,
-                                                                  int nblocks, int *__restrict__ counts) {
+// every thread of the block calls this with the mask of its item (0 past the end)
+__device__ __forceinline__ void part_count_block(unsigned m, int nbins, int nblocks, int *__restrict__ counts) {
     __shared__ int c[32];
     if (threadIdx.x < 32) c[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * PART_BLOCK + threadIdx.x;
-    const unsigned m = i < n ? mask[i] : 0u;
     const int lane = threadIdx.x & (WAVE - 1);
     for (int b = 0; b < nbins; b++) {
         const unsigned long long bal = __ballot((m >> b) & 1u);
@@ -123,6 +75,61 @@ static __global__ __launch_bounds__(PART_BLOCK) void k_part_count(int n, const u
     }
     __syncthreads();
     if ((int)threadIdx.x < nbins) counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = c[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------ ownership
+// Wrap every owned atom into the global box and name the rank whose brick contains it.
+// mask[i] = 1 << bin: bin 0 = stays here, 1 + p = leaves for peer p.  An atom that would have to
+// jump over a brick (cannot happen while the halo exceeds the displacement between rebuilds) raises *err.
+template <typename real>
+__global__ __launch_bounds__(PART_BLOCK) void k_dd_classify(int n, real *__restrict__ x, DdDev<real> g, unsigned *__restrict__ mask,
+                                                            int *__restrict__ err, int nbins, int nblocks, int *__restrict__ counts) {
+    const int i = blockIdx.x * PART_BLOCK + threadIdx.x;
+    unsigned m = 0;
+    if (i < n) {
+        int c[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            real p = x[3 * (size_t)i + d];
+            p -= g.L[d] * floor(p / g.L[d]);
+            x[3 * (size_t)i + d] = p;
+            c[d] = min(max((int)floor(p / g.width[d]), 0), g.grid[d] - 1);
+        }
+        const int dest = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
+        int bin = g.rank_bin[dest];
+        if (bin < 0) { *err = 1; bin = 0; }
+        m = 1u << bin;
+        mask[i] = m;
+    }
+    part_count_block(m, nbins, nblocks, counts);
+}
+
+// Which neighbours need this owned atom as a ghost: bit dir_bin[k] for every direction k whose halo holds it.
+template <typename real>
+__global__ __launch_bounds__(PART_BLOCK) void k_dd_ghost_mask(int n, const real *__restrict__ x, DdDev<real> g, unsigned *__restrict__ mask,
+                                                              int nbins, int nblocks, int *__restrict__ counts) {
+    const int i = blockIdx.x * PART_BLOCK + threadIdx.x;
+    unsigned m = 0;
+    if (i < n) {
+        bool near_lo[3], near_hi[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const real p = x[3 * (size_t)i + d];
+            near_lo[d] = g.cut[d] && p < g.lo[d] + g.halo;
+            near_hi[d] = g.cut[d] && p >= g.hi[d] - g.halo;
+        }
+        for (int k = 0; k < g.ndirs; k++) {
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const int s = g.dir[k][d];
+                in = in && (s == 0 || (s > 0 ? near_hi[d] : near_lo[d]));
+            }
+            if (in) m |= 1u << g.dir_bin[k];
+        }
+        mask[i] = m;
+    }
+    part_count_block(m, nbins, nblocks, counts);
 }
 
 static __global__ __launch_bounds__(PART_BLOCK) void k_part_scatter(int n, const unsigned *__restrict__ mask, int nbins,

@@ -531,7 +531,12 @@ struct NbSystem {
     int idx_shift = 0;
 
     // Are all LJAtom records identical?  (One small kernel + an 8-byte read-back per load.)
+    // uniform_known: -1 = look at the atoms at every load; 0 / 1 = the caller vouches that the species set is mixed /
+    // single (emdee_dd_*: agreed once over all domains; atoms only change owner afterwards) and the scan + read-back are skipped
+    int uniform_known = -1;
+    emdee_lj_atom uni_first{0.f, 0.f};
     void detect_uniform_atoms(const emdee_lj_atom *atoms) {
+        if (uniform_known >= 0 && n_total > 0) { uniform_atoms = uniform_known == 1; return; }
         uniform_atoms = false;
         if (n_total == 0 || std::getenv("EMDEE_NO_UNIFORM")) return;
         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));
@@ -540,6 +545,7 @@ struct NbSystem {
         EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 5, flags.ptr + 5, sizeof(int), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        uni_first = first;
         if (ctx->host_flags[5] == 0 && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
             // the same fp operations as the per-pair path: (hs + hs)^2 and te * te in the kernel's type
