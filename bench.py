@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--dd", choices=["native", "torch"], default="native",
                     help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
                          "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
+    ap.add_argument("--no-probe", action="store_true", help="N > 1, native: skip the connectivity probe (emdee.jl_amd/dd_probe.py)")
+    ap.add_argument("--probe-timeout", type=float, default=150.0, help="N > 1, native: seconds the probe children may take")
     ap.add_argument("--launch-timeout", type=int, default=900, help="self-launched N > 1 runs: seconds before the ranks are stopped")
     ap.add_argument("--domains", type=int, default=0,
                     help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
@@ -219,6 +221,7 @@ def main():
 
     domain = None
     dd_engine = None
+    dd_probe = None
     if world == 1 and args.domains <= 1:
         pos, vel, atoms, L = make_box(pkg, args.cells, args.mixture)
         N_total = N_rank = pos.shape[0]
@@ -233,7 +236,18 @@ def main():
         if args.dd == "native" or world == 1:
             # the decomposition inside the library; every rank must get there, or all fall back together
             ok, err = 1, None
+            if world > 1 and not args.no_probe:
+                # a child of every rank steps a small box over RCCL first, under a time limit: a halo exchange that
+                # cannot complete waits for ever instead of failing, and only a child can be abandoned (dd_probe.py)
+                ok, note = pkg.dd.probe_over_rccl(world, rank, local_rank, dist, timeout=args.probe_timeout,
+                                                  precision=args.precision)
+                dd_probe = note if ok else "failed: " + note
+                if not ok:
+                    err = "connectivity probe: " + note
+                ok = int(ok)
             try:
+                if not ok:
+                    raise RuntimeError(err)
                 domain = pkg.DomainDecomposition.synthetic(args.cells, ndom, rank if world > 1 else None, dev, model,
                                                            precision=tdtype, skin=args.skin, mixture=args.mixture, pkg=pkg,
                                                            scaling=args.scaling, dist=dist)
@@ -340,7 +354,7 @@ def main():
         "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%s), velocity-Verlet dt=%g, skin %g"
                                % (rc, rs, " binary mixture" if args.mixture else "", N_total, shape, args.dt, args.skin),
                    "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "parallelism": parallelism,
-                   "decomposition": dd_engine,
+                   "decomposition": dd_engine, "decomposition_probe": dd_probe,
                    "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
                    "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
         "pair_interactions_per_sec": pairs * steps_per_sec,

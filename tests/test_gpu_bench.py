@@ -43,3 +43,27 @@ def test_native_decomposition_line_and_target_box():
     # the decomposed box is the same physical system: same energies per atom after the same number of steps
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
     assert d["energy_per_atom"]["kinetic"] == pytest.approx(one["energy_per_atom"]["kinetic"], rel=1e-9)
+
+
+def test_probe_child_speaks_the_protocol():
+    """dd_probe.py on its own (one rank: the in-process transport): `ID <hex>` first, `OK ...` last, exit code 0."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "emdee.jl_amd", "dd_probe.py"), "--world", "1", "--rank", "0",
+                        "--cells", "12", "--steps", "12"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    assert lines[0].startswith("ID ") and len(lines[0].split()[1]) == 256
+    ok = [l for l in lines if l.startswith("OK ")]
+    assert len(ok) == 1 and int(ok[0].split()[1]) == 4 * 12 ** 3 and int(ok[0].split()[4]) >= 2
+
+
+def test_two_ranks_on_one_gpu_fall_back_to_the_torch_driver():
+    """`bench.py --gpus 2` started the way the driver starts it (no launcher), both ranks on this box's one GPU.  RCCL
+    refuses two ranks on one device, so the connectivity probe fails on every rank, all of them agree, and the line
+    comes from the torch.distributed driver -- the fallback the multi-GPU run depends on, exercised end to end."""
+    d = _bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--cells", "12", "--target-cells", "0", "--steps", "8",
+               "--warmup", "4", "--probe-timeout", "120")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 12 ** 3
+    assert d["config"]["decomposition"].startswith("torch"), d["config"]
+    assert d["config"]["decomposition_probe"].startswith("failed"), d["config"]
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None
+    assert d["energy_per_atom"]["kinetic"] > 0.5
