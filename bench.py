@@ -70,6 +70,11 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged halo, for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU rehearsal, with --backend gloo)")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="with --share-gpu: give every rank its own NCCL_HOSTID, so that RCCL accepts several ranks on the "
+                         "one device and carries their messages over its TCP transport on the loopback interface -- the "
+                         "native decomposition with real ranks on a 1-GPU box (a correctness rehearsal: the rate says "
+                         "nothing about xGMI)")
     ap.add_argument("--cpu-sample-cells", type=int, default=63)
     ap.add_argument("--dd", choices=["native", "torch"], default="native",
                     help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
@@ -200,6 +205,9 @@ def main():
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if args.share_gpu:
         local_rank = 0                     # rehearsal on a 1-GPU box: all ranks on cuda:0 (needs --backend gloo)
+        if args.rccl_loopback:             # before anything loads librccl; the probe children inherit it
+            os.environ.update(NCCL_HOSTID="emdee-share-gpu-rank-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                              NCCL_NET_GDR_LEVEL="0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -183,7 +183,9 @@ static inline size_t brick_force_lds_bytes(int tile_cap, int own_cap) {
 template <class Shape, int THREADS>
 static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap, int stride, int G) {
     // + one row buffer (stride uint16) per G-lane group
-    return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * stride * 2;
+    // + the candidate rows of every own cell ({first slot, span} of its 9 tile rows, and one all-zero set for ghosts)
+    return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * stride * 2 +
+           (size_t)(Shape::NOC + 1) * 9 * 8;
 }
 
 // position of the e-th neighbour inside a row: blocks of 8 G entries, lane-major inside a block,
@@ -401,7 +403,7 @@ constexpr int BUILD2_FIELD = 16;                      // bits per tile row in a 
 // G = lanes that share one atom HERE; GL = lanes per atom of the force kernels, which fixes the lane-major row
 // layout (row_position<GL>) -- the two need not agree.
 template <typename real, class Shape, int THREADS, int G, int ALG = 1, int GL = G>
-__global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
+__global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_build(BrickArgs<real> a) {   // <= 80 VGPRs: three 512-thread workgroups per CU
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -451,6 +453,21 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         const int oc = brick_locate(T, o, ti, p);
         T.oinfo[o] = make_int2(p, (oc << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
+    // candidate rows per own cell: the 9 tile rows (dy, dz) of 3 cells around it, as {first tile slot, slots}; entry NOC
+    // is empty (atoms that own no row).  One table per brick instead of index arithmetic and two reads per atom and row.
+    int2 *rtab = reinterpret_cast<int2 *>(s_dyn + (size_t)a.tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(a.own_cap) +
+                                          (size_t)NGROUPS * a.stride * 2);
+    for (int i = tid; i < (Shape::NOC + 1) * 9; i += THREADS) {
+        const int oc = i / 9, r = i % 9;
+        int2 v = make_int2(0, 0);
+        if (oc < Shape::NOC) {
+            const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
+            const int tcr = ox + TX * ((oy + r % 3) + TY * (oz + r / 3));       // cell x-1 of tile row (dy, dz) = (r%3-1, r/3-1)
+            v.x = T.off[tcr];
+            v.y = T.off[tcr + 3] - v.x;
+        }
+        rtab[i] = v;
+    }
     __syncthreads();
 
     const int gl = lane & (G - 1);
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         return pass;
     };
     auto in_range = [&](const float4 &qi, int p, int c, int tcr) -> bool { return in_range_q(qi, tile[c], p, c, tcr); };
-    if constexpr (ALG == 3 || ALG == 5) {
+    if constexpr (ALG % 10 == 3 || ALG % 10 == 5) {   // ALG 13 / 15: the same with candidates dealt round-robin (below)
         // ALG 2 with a leaner candidate loop (the build is VALU-issue bound: 2.7 G wave-instructions per rebuild at
         // 10^7 atoms, profiles/r02): the trip count of a tile row is made WAVE-uniform (the longest chunk in the
         // wavefront; a lane whose chunk is shorter tests slots past its chunk and drops those bits afterwards), so
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
         // ALG 3: two 16-bit fields per word (a lane's chunk of a tile row holds <= 16 candidates); ALG 5: one 32-bit field per
         // word, for long cutoffs / dense boxes (rc = 3.5 sigma: 132 candidates per row, 17 per lane)
-        constexpr int FIELD = ALG == 3 ? BUILD2_FIELD : 32, PER = 32 / FIELD;
+        constexpr int FIELD = ALG % 10 == 3 ? BUILD2_FIELD : 32, PER = 32 / FIELD;
         constexpr int NROWS = 9, NWORDS = (NROWS + PER - 1) / PER;
         constexpr bool BAND = sizeof(real) == 8;              // fp32 boxes: the fp32 test is the definition of the set
 #ifndef EMDEE_BUILD_UNROLL
@@ -508,6 +525,27 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
         constexpr int UNR = EMDEE_BUILD_UNROLL;
         float nrl2 = -rl2, nmargin_v = BAND ? -a.margin : 0.f, margin_v = a.margin;
         asm volatile("" : "+v"(nrl2), "+v"(nmargin_v), "+v"(margin_v));   // loop-invariant operands stay in VGPRs
+#ifndef EMDEE_BUILD_ROWTAB
+#define EMDEE_BUILD_ROWTAB 1
+#endif
+        // The build is bound by VALU issue, and a third of its instructions were per-row bookkeeping (profiles/r02): the
+        // candidate rows of an atom come from the brick's row table (one ds_read_b64 each, immediate offsets), and the
+        // wave-uniform trip counts of all 9 rows are found at once -- lane gl of every group holds the chunk length of
+        // row gl, three max steps combine the groups of the wavefront, 9 v_readlane move the result to scalars.
+        constexpr bool RT = EMDEE_BUILD_ROWTAB != 0;
+#ifndef EMDEE_BUILD_STRIDED
+#define EMDEE_BUILD_STRIDED 1
+#endif
+        // Candidates are dealt to the lanes of a group round-robin (lane gl tests slots c0 + gl, c0 + gl + G, ...), not in
+        // contiguous chunks: in-range candidates come in runs along a tile row, so contiguous chunks gave some lanes all of
+        // a row's hits and others none -- and the emission loops below run as long as the busiest lane of the wavefront
+        // (measured: emission 0.92 ms of a 2.87 ms build, more than the distance tests).  The 8 lanes of a group also read
+        // 128 contiguous bytes per step.
+        // The rows then list slots G apart in consecutive entries: fine for the force kernels that read 8-byte plane values
+        // or 16-byte records with 4 lanes per atom, an 8-way LDS bank conflict for 32-byte records read by 8 lanes (measured
+        // on the rc = 3.5 mixture: build 8.1 -> 6.6 ms, force 4.1 -> 6.0 ms) -- the host picks ALG 13/15 only for the former.
+        constexpr bool STRIDED = RT && EMDEE_BUILD_STRIDED != 0 && ALG >= 10;
+        constexpr int LOG2G = G == 8 ? 3 : 4, KSTEP = STRIDED ? G : 1;
         for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
             const int o = ob + gid;
             const bool have = o < n_own;
@@ -515,24 +553,62 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
             const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
             const int ti = info.y & 0xffff, p = info.x, oc = info.y >> 20;
             const bool act = have && ((info.y >> 16) & 1) != 0;   // ghosts own no row
-            const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const float4 qi = tile[ti];
             unsigned short *row = a.nbr + (size_t)p * a.stride;
             for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
             unsigned word[NWORDS];
             int cbase[NROWS];
+            const int2 *rt = rtab + (act ? oc : Shape::NOC) * 9;
+            int2 rv_next = make_int2(0, 0);
+            int trips_of[NROWS];
+            if constexpr (RT) {
+                rv_next = rt[0];
+                // chunk length of row gl (G = 8: rows 0..7 in the lanes, row 8 apart; G = 16: lanes 0..8 hold all nine)
+                int cv = (int)((unsigned)(rt[min(gl, NROWS - 1)].y + G - 1) / (unsigned)G);
+                int c8 = (int)((unsigned)(rt[NROWS - 1].y + G - 1) / (unsigned)G);
+                if constexpr (G == 8) {
+                    cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+                    c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
+                }
+                // across the four 16-lane rows with the gfx950 row / half swaps (no LDS, no address registers)
+                auto rows_max = [](int v) {
+                    auto q = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+                    v = max((int)q[0], (int)q[1]);
+                    q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+                    return max((int)q[0], (int)q[1]);
+                };
+                cv = rows_max(cv);
+                if constexpr (G == 8) c8 = rows_max(c8);
+#pragma unroll
+                for (int r = 0; r < NROWS; r++) {
+                    const int m = (G == 8 && r == NROWS - 1) ? __builtin_amdgcn_readlane(c8, 0) : __builtin_amdgcn_readlane(cv, r);
+                    trips_of[r] = (m + UNR - 1) & ~(UNR - 1);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < NROWS; r++) {
-                const int dy = r % 3 - 1, dz = r / 3 - 1;
-                const int tcr = ox + TX * ((oy + 1 + dy) + TY * (oz + 1 + dz));   // cell x-1 of that tile row
-                const int c0 = T.off[tcr];
-                const int span = act ? T.off[tcr + 3] - c0 : 0;                    // cells x-1, x, x+1: contiguous
-                const int chunk = (span + G - 1) / G;                               // <= BUILD2_FIELD (host check)
-                const int first = gl * chunk;
-                const int lim = min(chunk, span - first);                           // my candidates; may be <= 0
+                int tcr = 0, c0, span;
+                if constexpr (RT) {
+                    c0 = rv_next.x; span = rv_next.y;
+                    if (r + 1 < NROWS) rv_next = rt[r + 1];                        // one row ahead of its use
+                } else {
+                    const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
+                    tcr = ox + TX * ((oy + r % 3) + TY * (oz + r / 3));           // cell x-1 of tile row (dy, dz) = (r%3-1, r/3-1)
+                    c0 = T.off[tcr];
+                    span = act ? T.off[tcr + 3] - c0 : 0;                           // cells x-1, x, x+1: contiguous
+                }
+                const int chunk = (int)((unsigned)(span + G - 1) / (unsigned)G);    // <= BUILD2_FIELD (host check)
+                const int first = STRIDED ? gl : (int)__umul24((unsigned)gl, (unsigned)chunk);
+                // my candidates (may be <= 0 in the chunked form): slots cb + k KSTEP, k < lim
+                const int lim = STRIDED ? (int)((unsigned)(span - gl + G - 1) >> LOG2G) : min(chunk, span - first);
                 const int cb = c0 + first;
-                cbase[r] = cb - (r % PER) * FIELD;
-                const int trips = (wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1);   // scalar (chunk is the same in all lanes of a group); unrolled UNR times
+                cbase[r] = cb - (r % PER) * FIELD * KSTEP;
+                // scalar (chunk is the same in all lanes of a group); unrolled UNR times
+#ifdef EMDEE_BUILD_ABLATE      // timing experiments only (the lists are wrong): 1 no candidate loop, 2 no emission, 4 no flush
+                const int trips = (EMDEE_BUILD_ABLATE & 1) ? 0 : (RT ? trips_of[r] : ((wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1)));
+#else
+                const int trips = RT ? trips_of[r] : ((wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1));
+#endif
                 unsigned bits = 0;
                 const float4 *cand = tile + cb;
                 // d^2 - r_list^2 of candidate q, accumulated from -r_list^2
@@ -546,7 +622,12 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                 // slots of the lane's own chunk: what lies past it is dropped below and may not be a record
                 auto exact = [&](float &t, const float4 &q, int k) {
                     if (__builtin_fabsf(t) <= margin_v && k < lim) {
-                        const int c = cb + k;
+                        const int c = cb + k * KSTEP;
+                        if constexpr (RT) {                                  // rare path: the tile row is worked out here, not per row
+                            int occ = oc;
+                            asm volatile("" : "+v"(occ));
+                            tcr = occ % BX + TX * (((occ / BX) % BY + r % 3) + TY * (occ / (BX * BY) + r / 3));
+                        }
                         const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
                         const int sh = T.shift[tc];
                         const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(q.w)];
@@ -570,7 +651,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     float4 q[UNR];
                     float t[UNR];
 #pragma unroll
-                    for (int u = 0; u < UNR; u++) q[u] = cand[k + u];
+                    for (int u = 0; u < UNR; u++) q[u] = cand[(k + u) * KSTEP];
                     // (keeps the whole 16-byte records alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
                     if constexpr (!BAND) {
 #pragma unroll
@@ -591,10 +672,18 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
                     for (int u = 0; u < UNR; u++) shift_in(t[u]);
                 }
                 // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
-                bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & (lim >= 32 ? ~0u : ((1u << lim) - 1u))) : 0u;
+                if constexpr (RT && FIELD < 32)                                     // one v_bfe_u32: bits [32-trips, 32-trips+lim)
+                    bits = __builtin_amdgcn_ubfe(__builtin_bitreverse32(bits), (unsigned)(32 - trips), (unsigned)max(lim, 0));
+                else
+                    bits = lim > 0 ? ((__builtin_bitreverse32(bits) >> (32 - trips)) & (lim >= 32 ? ~0u : ((1u << lim) - 1u))) : 0u;
                 if (r == 4) {                                                       // the atom itself
-                    const int ks = ti - cb;
-                    if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
+                    if constexpr (STRIDED) {
+                        const int d = ti - c0;                                      // >= 0: the atom's cell is the middle one of row 4
+                        if ((d & (G - 1)) == gl) bits &= ~(1u << (d >> LOG2G));
+                    } else {
+                        const int ks = ti - cb;
+                        if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
+                    }
                 }
                 if (r % PER) word[r / PER] |= bits << ((r % PER) * FIELD);
                 else word[r / PER] = bits;
@@ -625,15 +714,23 @@ __global__ __launch_bounds__(THREADS) void k_brick_build(BrickArgs<real> a) {
 #pragma unroll
             for (int w = 0; w < NWORDS; w++) {
                 unsigned W = word[w];
+#ifdef EMDEE_BUILD_ABLATE
+                if (EMDEE_BUILD_ABLATE & 2) W = 0;
+#endif
                 const int cA = cbase[PER * w] << a.idx_shift, cB = ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0) << a.idx_shift;
+                const int kshift = a.idx_shift + (STRIDED ? LOG2G : 0);          // bit k of a field is slot cb + k KSTEP
                 while (W) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
-                    rowbuf[min(e, last)] = (unsigned short)((k << a.idx_shift) + ((PER == 2 && k >= FIELD) ? cB : cA));
+                    rowbuf[min(e, last)] = (unsigned short)((k << kshift) + ((PER == 2 && k >= FIELD) ? cB : cA));
                     e++;
                 }
             }
+#ifdef EMDEE_BUILD_ABLATE
+            if (have && !(EMDEE_BUILD_ABLATE & 4)) {
+#else
             if (have) {
+#endif
                 constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
                 for (int c = gl * EPL; c < a.stride; c += G * EPL) {
                     const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7

@@ -480,6 +480,12 @@ struct NbSystem {
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
                         if (build_alg == 3) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 3, V::G>;
                         if (build_alg == 5) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 5, V::G>;
+                        // round-robin candidates (brick.hpp): when the force kernels read plane values or 16-byte records with 4 lanes per atom
+                        if constexpr (V::G == 4) {
+                            const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !std::getenv("EMDEE_BUILD_CHUNKED");
+                            if (build_alg == 3 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 13, V::G>;
+                            if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
+                        }
                     }
                     lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
                     allow_big_lds(kernel, lds_build_bytes);

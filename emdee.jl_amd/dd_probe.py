@@ -9,7 +9,7 @@ limit; a child that does not answer is killed and all ranks agree to use the tor
 
 Protocol (stdin/stdout, text): rank 0 prints `ID <256 hex digits>` (the RCCL unique id, which must be generated in
 the process that will serve the bootstrap); the parent hands that line to every other rank's child on stdin.  Every
-child ends with `OK <n_global> <owned> <potential energy> <rebuilds>` and exit code 0, or a traceback and exit code 1.
+child ends with `OK <n_global> <owned> <potential energy> <rebuilds> <kinetic energy>` and exit code 0, or a traceback and exit code 1.
 
     python emdee.jl_amd/dd_probe.py --world 8 --rank 3 --device 3 [--cells 36] [--steps 24] [--precision f64]
 """
@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
     ap.add_argument("--rc", type=float, default=2.5)
     ap.add_argument("--mixture", action="store_true")
+    ap.add_argument("--in-process", action="store_true",
+                    help="all --world domains in this one process (device copies instead of RCCL): the reference a "
+                         "multi-process run of the same grid is compared with")
     args = ap.parse_args()
 
     sys.path.insert(0, ROOT)
@@ -40,7 +43,9 @@ def main():
     torch.cuda.set_device(args.device)
     dev = torch.device("cuda", args.device)
 
-    if args.rank == 0:
+    if args.in_process:
+        uid = None
+    elif args.rank == 0:
         uid = pkg.DomainDecomposition.unique_id()
         print("ID " + uid.hex(), flush=True)
     else:
@@ -50,9 +55,9 @@ def main():
         uid = bytes.fromhex(line[1])
 
     model = pkg.LennardJonesModel(args.rc, args.rc - 0.5)
-    dd = pkg.DomainDecomposition.synthetic(args.cells, args.world, args.rank, dev, model,
+    dd = pkg.DomainDecomposition.synthetic(args.cells, args.world, None if args.in_process else args.rank, dev, model,
                                            precision=torch.float64 if args.precision == "f64" else torch.float32,
-                                           mixture=args.mixture, pkg=pkg, unique_id=uid)
+                                           mixture=args.mixture, pkg=pkg, unique_id=uid, raw_velocities=True)
     dd.step_(args.steps, 0.005, 6)          # a rebuild (migration + new ghosts) every 6 steps, batches in between
     dd.step_(args.steps, 0.005, 0)          # and the displacement-triggered form the benchmark runs
     ep, ek, vir = dd.totals()               # all-reduced over the ranks inside the library
@@ -60,7 +65,7 @@ def main():
     st = dd.stats()
     if not (ep == ep and ek == ek and ek > 0.0):
         raise SystemExit("dd_probe: energies are not finite (%r, %r)" % (ep, ek))
-    print("OK %d %d %.12g %d" % (dd.n_global, dd.n_owned, ep, st["rebuilds"]), flush=True)
+    print("OK %d %d %.12g %d %.12g" % (dd.n_global, dd.n_owned, ep, st["rebuilds"], ek), flush=True)
     dd.close()
 
 

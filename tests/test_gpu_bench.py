@@ -67,3 +67,21 @@ def test_two_ranks_on_one_gpu_fall_back_to_the_torch_driver():
     assert d["config"]["decomposition_probe"].startswith("failed"), d["config"]
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
     assert d["energy_per_atom"]["kinetic"] > 0.5
+
+
+def test_two_ranks_over_rccl_on_one_gpu():
+    """The native decomposition with two real ranks: `--rccl-loopback` gives each rank its own NCCL_HOSTID, RCCL then
+    accepts both on this box's one device and carries the halo over its TCP transport.  The probe must pass, the line
+    must come from emdee_dd_* over RCCL send/recv, the second (target) box must be measured, and the physics must be
+    that of the undivided box."""
+    d = _bench("--gpus", "2", "--share-gpu", "--rccl-loopback", "--backend", "gloo", "--cells", "16", "--target-cells", "20",
+               "--steps", "8", "--warmup", "4", "--probe-timeout", "240")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 16 ** 3
+    assert d["config"]["decomposition"].startswith("native") and "RCCL" in d["config"]["decomposition"], d["config"]
+    assert d["config"]["decomposition_probe"].startswith("OK "), d["config"]
+    t = d["target_box"]
+    assert "error" not in t, t
+    assert t["atoms"] == 4 * 20 ** 3 and t["steps_per_sec"] > 0
+    one = _bench("--cells", "16", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
+    assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
+    assert d["energy_per_atom"]["kinetic"] == pytest.approx(one["energy_per_atom"]["kinetic"], rel=1e-9)

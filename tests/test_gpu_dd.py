@@ -1,11 +1,15 @@
 """GPU tests of the decomposition behind the C ABI (emdee_dd_*): migration, ghost
 selection, per-step halo messages with the rebuild request riding on them, batches of queued steps with
-device-side guard words.  The one-GPU test box cannot host two RCCL ranks, so the whole decomposition runs
-in ONE process on cuda:0 (n_local = world: the transport is device-to-device copies between the domains'
-streams; everything else is the production path) and the trajectory must match the CPU oracle on the
-undivided periodic box."""
+device-side guard words.  Most tests run the whole decomposition in ONE process on cuda:0 (n_local = world: the
+transport is device-to-device copies between the domains' streams; everything else is the production path) and the
+trajectory must match the CPU oracle on the undivided periodic box.  The last test runs real ranks -- separate
+processes, ncclSend/ncclRecv -- on the one device (RCCL's TCP transport; see profiles/rccl_ranks_one_gpu.py)."""
+import os
+
 import numpy as np
 import pytest
+
+from .conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -212,3 +216,16 @@ def test_dd_binary_mixture_long_cutoff(emdee, oracle):
     assert np.abs(f - ref["f"]).max() < 1e-6 * np.abs(ref["f"]).max()
     e1 = dd.totals()
     assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
+
+
+@pytest.mark.parametrize("world,extra", [(2, []), (4, []), (3, ["--cells", "30"]),
+                                         (2, ["--precision", "f32", "--mixture", "--rc", "3.5", "--cells", "20"])])
+def test_ranks_over_rccl_match_the_in_process_run(world, extra):
+    """profiles/rccl_ranks_one_gpu.py: `world` separate processes, one communicator rank each, halo over ncclSend/ncclRecv
+    (RCCL's TCP transport: a distinct NCCL_HOSTID per rank lets them share this box's one device) against the same grid
+    stepped inside one process with device copies: atoms, rebuild count and all-reduced energies must agree."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "rccl_ranks_one_gpu.py"), "--world", str(world),
+                        "--timeout", "240"] + extra, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0 and "MATCH" in r.stdout and "MISMATCH" not in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
