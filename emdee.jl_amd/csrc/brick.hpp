@@ -620,9 +620,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 };
                 // rounding band (fp64 boxes): decided with the exact fp64 records, for the lanes concerned -- and only for
                 // slots of the lane's own chunk: what lies past it is dropped below and may not be a record
-                auto exact = [&](float &t, const float4 &q, int k) {
+                auto exact = [&](float &t, int gpj, int k) {
                     if (__builtin_fabsf(t) <= margin_v && k < lim) {
-                        const int c = cb + k * KSTEP;
+                        int kq = k;
+                        asm volatile("" : "+s"(kq));                         // (worked out here, not carried through the loop)
+                        const int c = cb + kq * KSTEP;
                         if constexpr (RT) {                                  // rare path: the tile row is worked out here, not per row
                             int occ = oc;
                             asm volatile("" : "+v"(occ));
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                         }
                         const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
                         const int sh = T.shift[tc];
-                        const Rec<real> ri = a.rec[p], rj = a.rec[__float_as_int(q.w)];
+                        const Rec<real> ri = a.rec[p], rj = a.rec[gpj];
                         const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
                         const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
                         const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                         for (int u = 1; u < UNR; u++) tm = __builtin_fminf(tm, __builtin_fabsf(t[u]));
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tm <= margin_v) != 0, 0)) {
 #pragma unroll
-                            for (int u = 0; u < UNR; u++) exact(t[u], q[u], k + u);
+                            for (int u = 0; u < UNR; u++) exact(t[u], __float_as_int(q[u].w), k + u);
                         }
                     }
 #pragma unroll
@@ -709,21 +711,24 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             // per hit); the lane-major block layout the force kernels read (row_position) is produced while the row is
             // flushed, each 16-byte output chunk gathering its 8 entries.  A row that overflows the stride keeps
             // overwriting its last slot: the host sees the count, grows the stride and builds again.
-            unsigned e = (unsigned)(incl - mine);
-            const unsigned last = ustride - 1u;
+            // (a running pointer clamped to the row's last slot; the opaque use of W keeps the loop from being rewritten as a
+            // counted one, which costs a decrement and a compare per hit instead of the compare with zero)
+            unsigned short *ep = rowbuf + (unsigned)(incl - mine), *const ep_last = rowbuf + (ustride - 1u);
 #pragma unroll
             for (int w = 0; w < NWORDS; w++) {
                 unsigned W = word[w];
 #ifdef EMDEE_BUILD_ABLATE
                 if (EMDEE_BUILD_ABLATE & 2) W = 0;
 #endif
-                const int cA = cbase[PER * w] << a.idx_shift, cB = ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0) << a.idx_shift;
+                int cA = cbase[PER * w] << a.idx_shift, cB = ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0) << a.idx_shift;
+                asm volatile("" : "+v"(cA), "+v"(cB));                             // shifted once, here
                 const int kshift = a.idx_shift + (STRIDED ? LOG2G : 0);          // bit k of a field is slot cb + k KSTEP
                 while (W) {
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
-                    rowbuf[min(e, last)] = (unsigned short)((k << kshift) + ((PER == 2 && k >= FIELD) ? cB : cA));
-                    e++;
+                    asm volatile("" : "+v"(W));
+                    *(ep < ep_last ? ep : ep_last) = (unsigned short)((k << kshift) + ((PER == 2 && k >= FIELD) ? cB : cA));
+                    ep++;
                 }
             }
 #ifdef EMDEE_BUILD_ABLATE
