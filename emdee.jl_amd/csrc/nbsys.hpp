@@ -116,7 +116,8 @@ struct NbSystem {
     DevBuf<Rec<real>> rec, rec2;
     DevBuf<float> te, te2;
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
-    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, tmp, count, fill, nbr, cnt, flags, img, img2;
+    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, count, fill, nbr, cnt, flags, img, img2;
+    DevBuf<int2> tmp2;                    // {id, sort key} in arrival order inside each cell (bin)
     DevBuf<unsigned short> nbr16;
     DevBuf<int> btab;                     // per-brick tables of the current list (k_brick_tables)
     bool btab_valid = false;
@@ -215,7 +216,7 @@ struct NbSystem {
         if (velocities) { vel.ensure(3 * pitch); vel2.ensure(3 * pitch); }
         if (masses) { im.ensure(pitch); im2.ensure(pitch); }
         perm.ensure(n + 1); perm2.ensure(n + 1); inv_perm.ensure(n + 1); img.ensure(n + 1); img2.ensure(n + 1);
-        cell_of.ensure(n + 1); cell_sorted.ensure(n + 1); order.ensure(n + 1); tmp.ensure(n + 1); cnt.ensure(n + 1);
+        cell_of.ensure(n + 1); cell_sorted.ensure(n + 1); order.ensure(n + 1); cnt.ensure(n + 1);
         if (flags.ensure(16)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 16 * sizeof(int), stream()));
         partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
     }
@@ -231,10 +232,11 @@ struct NbSystem {
         hipLaunchKernelGGL((k_cell_assign<real, Src>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
                            cell_of.ptr, count.ptr);
         scanner.run(count.ptr, ncell + 1, stream());   // count[] becomes start[]
-        hipLaunchKernelGGL(k_cell_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, 0, count.ptr,
-                           fill.ptr, tmp.ptr);
-        hipLaunchKernelGGL(k_cell_rankfix, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, 0, count.ptr,
-                           tmp.ptr, key, order.ptr);
+        tmp2.ensure(n + 1);
+        hipLaunchKernelGGL(k_cell_scatter_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
+                           fill.ptr, key, tmp2.ptr);
+        hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
+                           tmp2.ptr, order.ptr);
     }
     const int *start() const { return count.ptr; }
 
