@@ -172,3 +172,41 @@ def test_ten_million_atoms_fp32_properties(emdee, dev):
     assert md.nbr_stats()["builds"] >= 4 and md.nbr_stats()["max_count"] <= md.nbr_stats()["capacity"]
     assert abs(md.count_pairs() / (0.5 * N) - 52.36) < 2.0
     assert 2.0 * ek1 / (3 * N - 3) > 0.5                                   # the lattice is melting, not exploding
+
+
+def test_same_box_with_very_different_density_profiles(emdee, oracle, dev):
+    """Three configurations of the same box through one operator handle: uniform, a third of the atoms crowded into one
+    corner (twice the density the first list was sized for: LDS tile capacity, row stride and build variant all have
+    to be re-planned), then dilute again.  Neighbour set and forces must be the oracle's each time."""
+    E = emdee
+    rng = np.random.default_rng(11)
+    N, L, rc, rs, skin = 24000, 36.0, 2.5, 2.0, 0.3
+    model = E.LennardJonesModel(rc, rs)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    tiles = E.nonbonded_computation_tiles(N)
+
+    def jittered_grid(n, lo, hi):                                  # n points on a jittered cubic grid inside [lo, hi)^3: no overlaps
+        m = int(np.ceil(n ** (1.0 / 3.0)))
+        g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), axis=-1).reshape(-1, 3)[:n]
+        h = (hi - lo) / m
+        return lo + (g + 0.5) * h + rng.uniform(-0.15, 0.15, size=(n, 3)) * h
+
+    uniform = jittered_grid(N, 0.0, L)
+    crowded = uniform.copy()
+    crowded[:N // 3] = jittered_grid(N // 3, 0.0, 16.0)            # ~2 atoms per sigma^3 in the corner, spacing 0.8 sigma
+    crowded[N // 3:] = jittered_grid(N - N // 3, 0.0, L)           # (overlaps between the two sets are possible: forces just get large)
+    # keep every pair apart: drop the second set's atoms that fall inside the crowded corner
+    inside = np.all(crowded[N // 3:] < 16.5, axis=1)
+    crowded[N // 3:][inside] = rng.uniform(17.0, L - 0.5, size=(int(inside.sum()), 3))
+    dilute = jittered_grid(N, 0.0, L)
+    for k, x in enumerate((uniform, crowded, dilute)):
+        f = torch.zeros((N, 3), dtype=torch.float64, device=dev)
+        E.compute_nonbonded_(f, None, None, E.cu(x, dev), L, tiles, model, E.cu(atoms, dev), E.Val(E.FORCES))
+        got = _rows(*tiles.neighbor_lists())
+        want = _oracle_rows(oracle, x, L, rc + skin)
+        for i in range(N):
+            assert np.array_equal(got[i], want[i]), "configuration %d, row %d differs" % (k, i)
+        fo, _, _ = oracle.nonbonded_cells(x.astype(np.float64), L, oracle.model(rc, rs), atoms)
+        scale = np.abs(fo).max()
+        assert np.abs(f.cpu().numpy() - fo).max() <= 1e-9 * scale
+    assert tiles.stats()["builds"] >= 3
