@@ -533,6 +533,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         // wave-uniform trip counts of all 9 rows are found at once -- lane gl of every group holds the chunk length of
         // row gl, three max steps combine the groups of the wavefront, 9 v_readlane move the result to scalars.
         constexpr bool RT = EMDEE_BUILD_ROWTAB != 0;
+        // an odd trip count ends with a single-candidate step instead of being rounded up (row spans of ~53 slots over 8
+        // lanes give 7 trips: rounding to 8 tested 14 % more slots than there are)
+        constexpr bool TAIL = RT && UNR == 2;
 #ifndef EMDEE_BUILD_STRIDED
 #define EMDEE_BUILD_STRIDED 1
 #endif
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
 #pragma unroll
                 for (int r = 0; r < NROWS; r++) {
                     const int m = (G == 8 && r == NROWS - 1) ? __builtin_amdgcn_readlane(c8, 0) : __builtin_amdgcn_readlane(cv, r);
-                    trips_of[r] = (m + UNR - 1) & ~(UNR - 1);
+                    trips_of[r] = TAIL ? m : ((m + UNR - 1) & ~(UNR - 1));
                 }
             }
 #pragma unroll
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 // other waves' arithmetic, and nothing is carried from trip to trip (no register rotation).  The band test
                 // of the group is one compare of the smallest |t| with the margin.
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int k = 0; k < trips; k += UNR) {                              // (reads past the chunk / the tile: harmless)
+                for (int k = 0; k + (TAIL ? 1 : 0) < trips; k += UNR) {             // (reads past the chunk / the tile: harmless)
                     float4 q[UNR];
                     float t[UNR];
 #pragma unroll
@@ -672,6 +675,16 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     }
 #pragma unroll
                     for (int u = 0; u < UNR; u++) shift_in(t[u]);
+                }
+                if (TAIL && (trips & 1)) {
+                    const float4 q = cand[(trips - 1) * KSTEP];
+                    if constexpr (!BAND) asm volatile("" : : "v"(q.w));
+                    float t = dist(q);
+                    if constexpr (BAND) {
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabsf(t) <= margin_v) != 0, 0))
+                            exact(t, __float_as_int(q.w), trips - 1);
+                    }
+                    shift_in(t);
                 }
                 // candidate k sits at bit trips-1-k: reverse, drop what lies past my chunk
                 if constexpr (RT && FIELD < 32)                                     // one v_bfe_u32: bits [32-trips, 32-trips+lim)
