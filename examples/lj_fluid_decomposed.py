@@ -28,6 +28,11 @@ if world > 1:                                                    # one rank per 
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     domains = world
+    # a small decomposed box stepped over RCCL by a child of every rank, under a time limit: a halo exchange that
+    # cannot complete waits for ever instead of failing, and only a child can be abandoned (emdee.jl_amd/dd_probe.py)
+    ok, note = E.dd.probe_over_rccl(world, rank, torch.cuda.current_device(), dist, timeout=150.0)
+    if not ok:
+        raise SystemExit("rank %d: the decomposition cannot run over RCCL here (%s)" % (rank, note))
 dev = torch.device("cuda", torch.cuda.current_device())
 
 model = E.LennardJonesModel(2.5, 2.0)
