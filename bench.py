@@ -17,6 +17,12 @@ GPU).  Default is STRONG scaling (BASELINE configs[2], north_star): the SAME --c
 into rank_grid(N) bricks and `value` = steps/s of that box.  `--scaling weak` gives every rank its own
 --cells^3 x 4-atom brick instead (`value` is still steps/s of the -- then N times larger -- box).
 
+N > 1 runs carry `target_box`: the same measurement on the north-star 293^3 x 4 = 100,615,028-atom box.
+Nothing in a multi-rank run is allowed to wait for ever: a child of every rank first steps a small decomposed box over
+RCCL under a time limit (emdee.jl_amd/dd_probe.py; failure -> all ranks take the torch.distributed driver together),
+the timed native run and the target-box leg have watchdogs (the latter prints the line without the leg), and the
+self-launched form bounds the whole child and repeats it once on the torch driver.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (lj_force_nbr) with HIP events
 recorded on its own stream inside the timed region; `cpu_baseline` times the CPU oracle on the host
 cores on a bounded sample of the same box.
@@ -80,7 +86,9 @@ def parse_args():
                     help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
                          "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
     ap.add_argument("--no-probe", action="store_true", help="N > 1, native: skip the connectivity probe (emdee.jl_amd/dd_probe.py)")
-    ap.add_argument("--probe-timeout", type=float, default=150.0, help="N > 1, native: seconds the probe children may take")
+    ap.add_argument("--probe-timeout", type=float, default=240.0, help="N > 1, native: seconds the probe children may take")
+    ap.add_argument("--native-timeout", type=int, default=300, help="N > 1, native: seconds warm-up + timed steps may take")
+    ap.add_argument("--target-timeout", type=int, default=420, help="N > 1: seconds the second (target) box may take before the line is printed without it")
     ap.add_argument("--launch-timeout", type=int, default=900, help="self-launched N > 1 runs: seconds before the ranks are stopped")
     ap.add_argument("--domains", type=int, default=0,
                     help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
@@ -294,6 +302,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    main_watchdog = None
+    if world > 1 and dd_engine is not None and dd_engine.startswith("native"):
+        # the probe has passed, so this is not expected to fire; if the timed run stalls all the same, leave with a status
+        # the self-launching parent answers with the torch driver, instead of waiting for somebody's time limit
+        import threading
+
+        def give_up():
+            print("rank %d: the native decomposition run did not finish within %d s" % (rank, args.native_timeout), file=sys.stderr, flush=True)
+            os._exit(17)
+        main_watchdog = threading.Timer(args.native_timeout, give_up)
+        main_watchdog.daemon = True
+        main_watchdog.start()
     run(args.warmup)
     fence()
     builds0 = engine.nbr_stats()["builds"]
@@ -303,6 +323,8 @@ def main():
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if main_watchdog is not None:
+        main_watchdog.cancel()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -437,6 +459,22 @@ def main():
         target_cells = 293 if (world > 1 and args.cells == 136 and not args.mixture and args.langevin == 0.0) else 0
     if dd_engine is not None and dd_engine.startswith("native") and scaling == "strong" and target_cells > args.cells:
         target = {"cells": target_cells}
+        # The headline measurement above is complete; this second box must not be able to lose it.  If the leg has not
+        # finished within --target-timeout seconds (a collective that never completes cannot be interrupted from inside),
+        # rank 0 prints the line with the leg marked as timed out and every rank leaves the process at once.
+        import threading
+        done = threading.Lock()
+
+        def bail():
+            if not done.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["target_box"] = dict(target, error="timed out after %d s" % args.target_timeout)
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.target_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             domain.close()
             del domain, engine
@@ -472,9 +510,12 @@ def main():
             big.close()
         except Exception as e:                                      # noqa: BLE001
             target["error"] = repr(e)
+        watchdog.cancel()
+        if not done.acquire(blocking=False):                        # the watchdog is printing: it also ends the process
+            time.sleep(30)
         out["target_box"] = target
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

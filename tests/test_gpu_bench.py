@@ -85,3 +85,13 @@ def test_two_ranks_over_rccl_on_one_gpu():
     one = _bench("--cells", "16", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
     assert d["energy_per_atom"]["kinetic"] == pytest.approx(one["energy_per_atom"]["kinetic"], rel=1e-9)
+
+
+def test_target_box_leg_cannot_lose_the_headline_line():
+    """--target-timeout 0: the watchdog of the second (target) box fires at once; the line must still be printed, once,
+    with the leg marked as timed out, and the ranks must leave with status 0."""
+    d = _bench("--gpus", "2", "--share-gpu", "--rccl-loopback", "--backend", "gloo", "--cells", "16", "--target-cells", "20",
+               "--steps", "8", "--warmup", "4", "--probe-timeout", "240", "--target-timeout", "0")
+    assert d["config"]["decomposition"].startswith("native")
+    assert "timed out" in d["target_box"].get("error", ""), d["target_box"]
+    assert d["value"] > 0 and d["energy_per_atom"]["kinetic"] > 0.5
