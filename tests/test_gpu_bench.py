@@ -74,8 +74,8 @@ def test_two_ranks_over_rccl_on_one_gpu():
     accepts both on this box's one device and carries the halo over its TCP transport.  The probe must pass, the line
     must come from emdee_dd_* over RCCL send/recv, the second (target) box must be measured, and the physics must be
     that of the undivided box."""
-    d = _bench("--gpus", "2", "--share-gpu", "--rccl-loopback", "--backend", "gloo", "--cells", "16", "--target-cells", "20",
-               "--steps", "8", "--warmup", "4", "--probe-timeout", "240")
+    d = _bench("--gpus", "2", "--share-gpu", "--rccl-loopback", "--cells", "16", "--target-cells", "20",
+               "--steps", "8", "--warmup", "4", "--probe-timeout", "240")     # torch.distributed on its default backend: RCCL too
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 16 ** 3
     assert d["config"]["decomposition"].startswith("native") and "RCCL" in d["config"]["decomposition"], d["config"]
     assert d["config"]["decomposition_probe"].startswith("OK "), d["config"]
