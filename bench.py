@@ -87,6 +87,8 @@ def parse_args():
                          "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
     ap.add_argument("--no-probe", action="store_true", help="N > 1, native: skip the connectivity probe (emdee.jl_amd/dd_probe.py)")
     ap.add_argument("--probe-timeout", type=float, default=240.0, help="N > 1, native: seconds the probe children may take")
+    ap.add_argument("--no-halo-trial", action="store_true", help="N > 1, native: keep the overlapped halo exchange without trying the in-order form")
+    ap.add_argument("--halo-trial-steps", type=int, default=12, help="N > 1, native: untimed steps per form of the halo exchange before the timed ones")
     ap.add_argument("--native-timeout", type=int, default=300, help="N > 1, native: seconds warm-up + timed steps may take")
     ap.add_argument("--target-timeout", type=int, default=420, help="N > 1: seconds the second (target) box may take before the line is printed without it")
     ap.add_argument("--launch-timeout", type=int, default=900, help="self-launched N > 1 runs: seconds before the ranks are stopped")
@@ -302,7 +304,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def choose_halo_mode(obj, k):
+        """N > 1, native: a few untimed steps with the halo exchange overlapped with the interior bricks (two launches,
+        events between streams) and a few with everything in order on the compute stream (one launch, no events); keep the
+        faster one for the timed steps.  Which wins depends on the size of a rank's domain and on the link."""
+        trial = {}
+        for name, on in (("overlapped", True), ("in order", False)):
+            obj.set_overlap_(on)
+            obj.step_(2, args.dt, args.rebuild_every)
+            fence()
+            t0 = time.perf_counter()
+            obj.step_(k, args.dt, args.rebuild_every)
+            fence()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[name] = 1e3 * tt.item() / k
+        best = min(trial, key=trial.get)
+        obj.set_overlap_(best == "overlapped")
+        return {"chosen": best, "trial_ms_per_step": trial, "trial_steps": k}
+
     main_watchdog = None
+    halo_mode = None
     if world > 1 and dd_engine is not None and dd_engine.startswith("native"):
         # the probe has passed, so this is not expected to fire; if the timed run stalls all the same, leave with a status
         # the self-launching parent answers with the torch driver, instead of waiting for somebody's time limit
@@ -316,6 +338,9 @@ def main():
         main_watchdog.start()
     run(args.warmup)
     fence()
+    if main_watchdog is not None and not args.no_halo_trial and os.environ.get("EMDEE_DD_OVERLAP") is None:
+        halo_mode = choose_halo_mode(domain, args.halo_trial_steps)
+        overlap = halo_mode["chosen"] == "overlapped"
     builds0 = engine.nbr_stats()["builds"]
     engine.profile_(True)
     fence()
@@ -384,7 +409,7 @@ def main():
         "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%s), velocity-Verlet dt=%g, skin %g"
                                % (rc, rs, " binary mixture" if args.mixture else "", N_total, shape, args.dt, args.skin),
                    "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "parallelism": parallelism,
-                   "decomposition": dd_engine, "decomposition_probe": dd_probe,
+                   "decomposition": dd_engine, "decomposition_probe": dd_probe, "halo_exchange": halo_mode,
                    "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
                    "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
         "pair_interactions_per_sec": pairs * steps_per_sec,
@@ -485,6 +510,8 @@ def main():
             k_w, k_t = min(args.warmup, 5), min(args.steps, 20)
             big.step_(k_w, args.dt, args.rebuild_every)
             fence()
+            if halo_mode is not None:
+                target["halo_exchange"] = choose_halo_mode(big, max(4, args.halo_trial_steps // 2))
             t0 = time.perf_counter()
             big.step_(k_t, args.dt, args.rebuild_every)
             fence()

@@ -501,5 +501,8 @@ int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, ui
 int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]) {
     return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->stats(out); });
 }
+int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->set_overlap(overlap != 0); });
+}
 
 }  // extern "C"

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
     ap.add_argument("--rc", type=float, default=2.5)
     ap.add_argument("--mixture", action="store_true")
+    ap.add_argument("--switch-overlap", action="store_true",
+                    help="second half of the steps without interior/boundary overlap (emdee_dd_set_overlap 0)")
     ap.add_argument("--in-process", action="store_true",
                     help="all --world domains in this one process (device copies instead of RCCL): the reference a "
                          "multi-process run of the same grid is compared with")
@@ -59,6 +61,8 @@ def main():
                                            precision=torch.float64 if args.precision == "f64" else torch.float32,
                                            mixture=args.mixture, pkg=pkg, unique_id=uid, raw_velocities=True)
     dd.step_(args.steps, 0.005, 6)          # a rebuild (migration + new ghosts) every 6 steps, batches in between
+    if args.switch_overlap:
+        dd.set_overlap_(False)              # exchange and one launch over all bricks, in order on the compute stream
     dd.step_(args.steps, 0.005, 0)          # and the displacement-triggered form the benchmark runs
     ep, ek, vir = dd.totals()               # all-reduced over the ranks inside the library
     torch.cuda.synchronize(dev)

@@ -72,3 +72,8 @@ owned_state!(dd::DomainDecomposition{T}, gids::HipArray{Int64,1}, positions::Hip
 set_langevin!(dd::DomainDecomposition, gamma, temperature; seed=0, first_step=0) =
     check(ccall((:emdee_dd_set_langevin, libemdee_hip), Int32, (Ptr{Cvoid}, Float64, Float64, UInt64, UInt64),
                 dd.handle, gamma, temperature, seed, first_step))
+
+# int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap);
+# true (default): interior bricks overlap the halo exchange; false: exchange and one launch over all bricks in order
+set_overlap!(dd::DomainDecomposition, on::Bool) =
+    check(ccall((:emdee_dd_set_overlap, libemdee_hip), Int32, (Ptr{Cvoid}, Int32), dd.handle, on ? 1 : 0))

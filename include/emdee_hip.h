@@ -305,6 +305,12 @@ int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, ui
 /* out[0] = rebuilds, out[1] = batches of queued steps, out[2] = queued steps cancelled by a rebuild request,
  * out[3] = atoms that changed owner (this process) */
 int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]);
+/* How a step meets its halo exchange.  1 (default): interior bricks while the messages travel on a communication stream,
+ * boundary bricks on a stream of their own when they have arrived.  0: pack, exchange, unpack and ONE launch over all
+ * bricks, in order on the compute stream -- no events, no split launch; cheaper when the messages are short next to the
+ * cross-stream bookkeeping (small domains).  Same results either way; collective (all ranks must choose alike only for
+ * speed, not for correctness).  Call between emdee_dd_step calls. */
+int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap);
 
 #ifdef __cplusplus
 }

@@ -33,12 +33,14 @@ def main():
     ap.add_argument("--precision", default="f64")
     ap.add_argument("--mixture", action="store_true")
     ap.add_argument("--rc", type=float, default=2.5)
+    ap.add_argument("--switch-overlap", action="store_true", help="the ranks run the second half without overlap (in-order exchange)")
     args = ap.parse_args()
     if args.world > 6:
         raise SystemExit("at most 6 processes may share the card on the GPU boxes")
 
     common = ["--world", str(args.world), "--device", "0", "--cells", str(args.cells), "--steps", str(args.steps),
               "--precision", args.precision, "--rc", str(args.rc)] + (["--mixture"] if args.mixture else [])
+    rank_only = ["--switch-overlap"] if args.switch_overlap else []      # (the in-process reference keeps the default)
     kids, logs = [], []
     deadline = time.monotonic() + args.timeout
 
@@ -59,7 +61,7 @@ def main():
             env.setdefault("NCCL_DEBUG", "WARN")
             log = open(os.path.join(ROOT, "gpurun_out", "rccl_rank%d.err" % r), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else subprocess.DEVNULL
             logs.append(log)
-            k = subprocess.Popen([sys.executable, PROBE, "--rank", str(r)] + common, env=env, stdin=subprocess.PIPE,
+            k = subprocess.Popen([sys.executable, PROBE, "--rank", str(r)] + common + rank_only, env=env, stdin=subprocess.PIPE,
                                  stdout=subprocess.PIPE, stderr=log, text=True, start_new_session=True)
             kids.append(k)
             if r == 0:

@@ -75,14 +75,17 @@ def test_two_ranks_over_rccl_on_one_gpu():
     must come from emdee_dd_* over RCCL send/recv, the second (target) box must be measured, and the physics must be
     that of the undivided box."""
     d = _bench("--gpus", "2", "--share-gpu", "--rccl-loopback", "--cells", "16", "--target-cells", "20",
-               "--steps", "8", "--warmup", "4", "--probe-timeout", "240")     # torch.distributed on its default backend: RCCL too
+               "--steps", "8", "--warmup", "4", "--probe-timeout", "240", "--halo-trial-steps", "2")   # torch.distributed on its default backend: RCCL too
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 16 ** 3
     assert d["config"]["decomposition"].startswith("native") and "RCCL" in d["config"]["decomposition"], d["config"]
     assert d["config"]["decomposition_probe"].startswith("OK "), d["config"]
+    h = d["config"]["halo_exchange"]                               # both forms of the step were tried before the timed run
+    assert h["chosen"] in ("overlapped", "in order") and set(h["trial_ms_per_step"]) == {"overlapped", "in order"}
     t = d["target_box"]
     assert "error" not in t, t
     assert t["atoms"] == 4 * 20 ** 3 and t["steps_per_sec"] > 0
-    one = _bench("--cells", "16", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
+    # the two trials took 2 x (2 + 2) untimed steps: the undivided run gets them as warm-up
+    one = _bench("--cells", "16", "--steps", "8", "--warmup", "12", "--no-cpu-baseline")
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
     assert d["energy_per_atom"]["kinetic"] == pytest.approx(one["energy_per_atom"]["kinetic"], rel=1e-9)
 

@@ -218,7 +218,7 @@ def test_dd_binary_mixture_long_cutoff(emdee, oracle):
     assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
 
 
-@pytest.mark.parametrize("world,extra", [(2, []), (4, []), (3, ["--cells", "30"]),
+@pytest.mark.parametrize("world,extra", [(2, []), (4, []), (3, ["--cells", "30"]), (4, ["--switch-overlap"]),
                                          (2, ["--precision", "f32", "--mixture", "--rc", "3.5", "--cells", "20"])])
 def test_ranks_over_rccl_match_the_in_process_run(world, extra):
     """profiles/rccl_ranks_one_gpu.py: `world` separate processes, one communicator rank each, halo over ncclSend/ncclRecv
