@@ -10,12 +10,13 @@ E = load_package()
 dev = torch.device("cuda", 0)
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 86
 model = E.LennardJonesModel(2.5, 2.0)
-dd = E.DomainDecomposition.synthetic(cells, 1, None, dev, model, skin=0.3, pkg=E)
+skin = float(os.environ.get("SKIN", "0.3"))
+dd = E.DomainDecomposition.synthetic(cells, 1, None, dev, model, skin=skin, pkg=E)
 pos, L = E.synthetic.fcc_positions(cells)
 N = pos.shape[0]
 vel = E.synthetic.velocities(N)
 atoms = E.lennard_jones_atoms(1.0, 1.0, N)
-md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev), skin=0.3)
+md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev), skin=skin)
 only = sys.argv[2] if len(sys.argv) > 2 else "both"
 for name, obj in (("dd, one domain", dd), ("plain integrator", md)):
     if only != "both" and not name.startswith(only):
