@@ -336,7 +336,9 @@ struct DdImpl : IDd {
     // Without overlap (emdee_dd_set_overlap 0), a process that holds ONE domain runs every exchange IN ORDER on its compute
     // stream: no event is recorded or waited for (each record / cross-stream wait pair leaves ~25 us of empty queue per
     // step).  Several domains in one process copy from each other's buffers and keep the events.
-    bool inline_exchange() const { return !overlap && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0); }
+    // The exchanges of a rebuild (counts, migrants, ghost rows) have nothing to overlap with and always go in order.
+    bool in_rebuild = false;
+    bool inline_exchange() const { return (!overlap || in_rebuild) && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0); }
     void record_packed(Domain<real> &d) {
         if (!inline_exchange()) EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
     }
@@ -516,6 +518,11 @@ struct DdImpl : IDd {
     }
 
     void redistribute(bool from_engines) {
+        struct Scope {
+            bool &f;
+            explicit Scope(bool &b) : f(b) { f = true; }
+            ~Scope() { f = false; }
+        } scope(in_rebuild);
         // ---- 0. caller-order copies of the integrated state
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
