@@ -96,6 +96,27 @@ def test_dd_trajectory_matches_oracle(emdee, oracle, world, rebuild_every, lange
     dd.close()
 
 
+@pytest.mark.parametrize("world", [1, 4])
+def test_dd_in_order_exchange_gives_the_same_trajectory(emdee, world):
+    """emdee_dd_set_overlap(0): pack, exchange, unpack and ONE launch over all bricks in order (for one domain per process
+    also without any event) -- the same states as the overlapped form with its interior / boundary launches, switched in
+    the middle of a run and back."""
+    E = emdee
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform=True)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    a, b = _build(E, world, pos, vel, atoms, L), _build(E, world, pos, vel, atoms, L)
+    b.set_overlap_(False)
+    a.step_(11, DT, 0); b.step_(11, DT, 0)
+    b.set_overlap_(True); a.set_overlap_(False)
+    a.step_(9, DT, 0); b.step_(9, DT, 0)
+    xa, va, fa = _gather(a, world, N)
+    xb, vb, fb = _gather(b, world, N)
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(fa, fb)
+    assert a.stats()["rebuilds"] == b.stats()["rebuilds"] >= 2
+    a.close(); b.close()
+
+
 def test_dd_langevin_single_call_matches_oracle(emdee, oracle):
     """Noise keyed by global atom id and step number: the decomposed run draws what the undivided run draws."""
     E = emdee
