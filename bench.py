@@ -18,10 +18,14 @@ into rank_grid(N) bricks and `value` = steps/s of that box.  `--scaling weak` gi
 --cells^3 x 4-atom brick instead (`value` is still steps/s of the -- then N times larger -- box).
 
 N > 1 runs carry `target_box`: the same measurement on the north-star 293^3 x 4 = 100,615,028-atom box.
-Nothing in a multi-rank run is allowed to wait for ever: a child of every rank first steps a small decomposed box over
-RCCL under a time limit (emdee.jl_amd/dd_probe.py; failure -> all ranks take the torch.distributed driver together),
-the timed native run and the target-box leg have watchdogs (the latter prints the line without the leg), and the
-self-launched form bounds the whole child and repeats it once on the torch driver.
+Nothing in a multi-rank run is allowed to wait for ever, and everything derives from ONE deadline (--deadline, 540 s from
+the start of the process the driver started: below the driver's 600 s): a child of every rank first steps a small
+decomposed box over RCCL under a time limit (emdee.jl_amd/dd_probe.py; failure -> all ranks take the torch.distributed
+driver together), the timed native run and the target-box leg have watchdogs (the latter prints the line without the
+leg), every limit is the smaller of its flag and what is left of the deadline minus a reserve for the stages behind it,
+and the self-launched form repeats a failed native run on the torch driver only if no line has been printed and enough
+time is left.  A line that the torch driver produced because the native decomposition failed says so: top-level
+`"degraded": "<reason>"`.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (lj_force_nbr) with HIP events
 recorded on its own stream inside the timed region; `cpu_baseline` times the CPU oracle on the host
@@ -86,12 +90,18 @@ def parse_args():
                     help="N > 1: native = emdee_dd_* (migration, ghosts, halo over RCCL and the batched step loop inside "
                          "libemdee_hip.so); torch = the host-side driver of emdee.jl_amd/domain.py over torch.distributed")
     ap.add_argument("--no-probe", action="store_true", help="N > 1, native: skip the connectivity probe (emdee.jl_amd/dd_probe.py)")
-    ap.add_argument("--probe-timeout", type=float, default=240.0, help="N > 1, native: seconds the probe children may take")
+    ap.add_argument("--deadline", type=float, default=540.0,
+                    help="seconds, from the start of the process the driver started, by which the JSON line must be out; every "
+                         "other limit below is clipped to what is left of it (the driver stops a run after 600 s)")
+    ap.add_argument("--retry-min", type=float, default=200.0,
+                    help="self-launched N > 1 runs: seconds that must be left for the failed native run to be repeated on --dd torch")
+    ap.add_argument("--degraded", default=None, help=argparse.SUPPRESS)   # reason handed to the torch-driver retry
+    ap.add_argument("--probe-timeout", type=float, default=90.0, help="N > 1, native: seconds the probe children may take")
     ap.add_argument("--no-halo-trial", action="store_true", help="N > 1, native: keep the overlapped halo exchange without trying the in-order form")
     ap.add_argument("--halo-trial-steps", type=int, default=12, help="N > 1, native: untimed steps per form of the halo exchange before the timed ones")
-    ap.add_argument("--native-timeout", type=int, default=300, help="N > 1, native: seconds warm-up + timed steps may take")
-    ap.add_argument("--target-timeout", type=int, default=420, help="N > 1: seconds the second (target) box may take before the line is printed without it")
-    ap.add_argument("--launch-timeout", type=int, default=900, help="self-launched N > 1 runs: seconds before the ranks are stopped")
+    ap.add_argument("--native-timeout", type=float, default=150.0, help="N > 1, native: seconds warm-up + timed steps may take")
+    ap.add_argument("--target-timeout", type=float, default=180.0, help="N > 1: seconds the second (target) box may take before the line is printed without it")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="self-launched N > 1 runs: seconds before the ranks are stopped (0: what is left of --deadline)")
     ap.add_argument("--domains", type=int, default=0,
                     help="one-GPU rehearsal of the native decomposition: cut the box into this many domains, all in this "
                          "process on cuda:0 (device-to-device halo copies instead of RCCL)")
@@ -104,13 +114,61 @@ def parse_args():
     return ap.parse_args()
 
 
-def self_launch(args):
+T_PROCESS_START = time.time()
+DEADLINE_ENV = "EMDEE_BENCH_DEADLINE_AT"
+
+
+class Budget:
+    """One wall-clock deadline for the whole run (absolute epoch seconds, inherited by the ranks a self-launched run
+    starts); every stage asks for min(its own flag, what is left minus a reserve for the stages behind it)."""
+
+    def __init__(self, args):
+        at = os.environ.get(DEADLINE_ENV)
+        self.at = float(at) if at else T_PROCESS_START + float(args.deadline)
+
+    def left(self):
+        return self.at - time.time()
+
+    def limit(self, want, reserve=0.0, floor=1.0):
+        return max(float(floor), min(float(want), self.left() - float(reserve)))
+
+
+def descendants(pid):
+    """PIDs of all living descendants of `pid` (children first), from the parent links in /proc."""
+    parent = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open("/proc/%s/stat" % name) as fh:
+                fields = fh.read().rsplit(")", 1)[1].split()                     # after the command name, which may hold spaces
+            parent[int(name)] = int(fields[1])
+        except (OSError, IndexError, ValueError):
+            continue
+    out, frontier = [], [pid]
+    while frontier:
+        nxt = [c for c, p in parent.items() if p in frontier]
+        out += nxt
+        frontier = nxt
+    return out
+
+
+def is_result_line(text):
+    return text.startswith('{"metric"')
+
+
+def self_launch(args, budget=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (this process has not
-    imported torch or touched the GPU; it only relays the child's output and exit code).  If the native decomposition
-    run fails or exceeds --launch-timeout, the ranks are started once more on the torch.distributed driver."""
+    imported torch or touched the GPU; it relays the child's output and exit code).  The child may take what is left of
+    the deadline.  If the native decomposition run fails WITHOUT having printed its line, and at least --retry-min
+    seconds are left, the ranks are started once more on the torch.distributed driver, which marks its line as degraded."""
     import signal
     import socket
     import subprocess
+    import threading
+
+    budget = budget or Budget(args)
+    printed = []
 
     def run(extra):
         s = socket.socket()
@@ -120,24 +178,58 @@ def self_launch(args):
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "8")
+        env[DEADLINE_ENV] = repr(budget.at - 10.0)                              # the ranks finish before their launcher gives up
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
-        child = subprocess.Popen(cmd, env=env, start_new_session=True)         # its own process group: killable as a whole
+               "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.environ.get("EMDEE_BENCH_RANK_SCRIPT", os.path.abspath(__file__))] + sys.argv[1:] + extra   # (the override: CPU tests of this launcher)
+        limit = budget.limit(args.launch_timeout if args.launch_timeout > 0 else 1e9, reserve=3.0)
+        child = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, text=True)   # its own process group: killable as a whole
+
+        def relay():
+            for ln in child.stdout:
+                if is_result_line(ln):
+                    if printed:                                                  # ONE line, whatever the ranks do
+                        continue
+                    printed.append(ln)
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+        t = threading.Thread(target=relay, daemon=True)
+        t.start()
         try:
-            return child.wait(timeout=args.launch_timeout)
+            rc = child.wait(timeout=limit)
         except subprocess.TimeoutExpired:
-            print("bench.py: the %d-rank run exceeded %d s and is being stopped" % (args.gpus, args.launch_timeout), file=sys.stderr)
+            print("bench.py: the %d-rank run exceeded %.0f s and is being stopped" % (args.gpus, limit), file=sys.stderr)
+            # torch.distributed.run gives every rank a process group of its own: killing the launcher's group alone would
+            # orphan ranks that are stuck in a wait, with the GPUs in their hands.  Collect the launcher's descendants while
+            # the parent links still exist, then stop exactly those processes.
+            victims = descendants(child.pid)
+            for pid in [child.pid] + victims:
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
             try:
-                os.killpg(child.pid, signal.SIGKILL)                             # exactly the group started above
+                os.killpg(child.pid, signal.SIGKILL)                             # and whatever else shares the launcher's group
             except ProcessLookupError:
                 pass
             child.wait()
-            return 124
+            rc = 124
+        t.join(timeout=5.0)
+        return rc
 
     rc = run([])
+    if printed:
+        return 0                                                                 # the line is out: nothing is repeated
     if rc != 0 and args.dd == "native":
-        print("bench.py: native decomposition run ended with status %d; once more with --dd torch" % rc, file=sys.stderr)
-        rc = run(["--dd", "torch"])
+        if budget.left() >= args.retry_min:
+            reason = "native decomposition run ended with status %d" % rc
+            print("bench.py: %s; once more with --dd torch" % reason, file=sys.stderr)
+            rc = run(["--dd", "torch", "--degraded", reason])
+            if printed:
+                return 0
+        else:
+            print("bench.py: native decomposition run ended with status %d and %.0f s are left: no second attempt"
+                  % (rc, budget.left()), file=sys.stderr)
     return rc
 
 
@@ -202,8 +294,10 @@ def cache_path(args):
 
 def main():
     args = parse_args()
+    budget = Budget(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args))
+        raise SystemExit(self_launch(args, budget))
+    import threading
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -231,6 +325,29 @@ def main():
             dist.init_process_group("gloo")
             cdev = torch.device("cpu")
 
+    # ONE line, printed once, by whoever gets there first: the normal end of main(), the target-box watchdog, or the
+    # last-resort timer that fires shortly before the deadline (it prints the line if the headline measurement is complete)
+    line = {"out": None, "lock": threading.Lock(), "printed": False}
+
+    def emit():
+        with line["lock"]:
+            if line["printed"] or line["out"] is None:
+                return line["printed"]
+            if rank == 0:
+                print(json.dumps(line["out"]), flush=True)
+            line["printed"] = True
+            return True
+
+    def last_resort():
+        done = emit()
+        print("rank %d: the deadline (%.0f s) is here; %s" % (rank, args.deadline, "line printed" if done else "no measurement to print"),
+              file=sys.stderr, flush=True)
+        os._exit(0 if done else 18)
+    if world > 1:
+        final_timer = threading.Timer(max(budget.left() - 4.0, 1.0), last_resort)
+        final_timer.daemon = True
+        final_timer.start()
+
     w = 8 if args.precision == "f64" else 4
     tdtype = torch.float64 if w == 8 else torch.float32
     ndtype = np.float64 if w == 8 else np.float32
@@ -240,6 +357,7 @@ def main():
     domain = None
     dd_engine = None
     dd_probe = None
+    degraded = args.degraded           # why the torch driver runs although the native decomposition was asked for
     if world == 1 and args.domains <= 1:
         pos, vel, atoms, L = make_box(pkg, args.cells, args.mixture)
         N_total = N_rank = pos.shape[0]
@@ -257,8 +375,8 @@ def main():
             if world > 1 and not args.no_probe:
                 # a child of every rank steps a small box over RCCL first, under a time limit: a halo exchange that
                 # cannot complete waits for ever instead of failing, and only a child can be abandoned (dd_probe.py)
-                ok, note = pkg.dd.probe_over_rccl(world, rank, local_rank, dist, timeout=args.probe_timeout,
-                                                  precision=args.precision)
+                ok, note = pkg.dd.probe_over_rccl(world, rank, local_rank, dist, precision=args.precision,
+                                                  timeout=budget.limit(args.probe_timeout, reserve=240.0, floor=20.0))
                 dd_probe = note if ok else "failed: " + note
                 if not ok:
                     err = "connectivity probe: " + note
@@ -281,6 +399,11 @@ def main():
                     raise SystemExit("native decomposition failed: %s" % err)
                 if err is not None:
                     print("rank %d: native decomposition unavailable (%s); falling back to --dd torch" % (rank, err), file=sys.stderr)
+                reasons = [err]
+                if dist is not None:                               # the line is rank 0's: it names a rank that failed
+                    reasons = [None] * world
+                    dist.all_gather_object(reasons, err)
+                degraded = next(("rank %d: %s" % (r, e) for r, e in enumerate(reasons) if e), "native decomposition unavailable")
                 domain = None
         if domain is None:
             domain = pkg.domain.DecomposedVerlet.synthetic(args.cells, world, rank, dev, model, precision=tdtype,
@@ -327,13 +450,14 @@ def main():
     halo_mode = None
     if world > 1 and dd_engine is not None and dd_engine.startswith("native"):
         # the probe has passed, so this is not expected to fire; if the timed run stalls all the same, leave with a status
-        # the self-launching parent answers with the torch driver, instead of waiting for somebody's time limit
-        import threading
+        # the self-launching parent answers with the torch driver (if time is left), instead of waiting for somebody's limit
+
+        native_limit = budget.limit(args.native_timeout, reserve=60.0, floor=10.0)
 
         def give_up():
-            print("rank %d: the native decomposition run did not finish within %d s" % (rank, args.native_timeout), file=sys.stderr, flush=True)
+            print("rank %d: the native decomposition run did not finish within %.0f s" % (rank, native_limit), file=sys.stderr, flush=True)
             os._exit(17)
-        main_watchdog = threading.Timer(args.native_timeout, give_up)
+        main_watchdog = threading.Timer(native_limit, give_up)
         main_watchdog.daemon = True
         main_watchdog.start()
     run(args.warmup)
@@ -429,6 +553,8 @@ def main():
                           "max_count": stats["max_count"], "capacity": stats["capacity"]},
         "energy_per_atom": {"potential": ep / N_energy, "kinetic": ek / N_energy},
     }
+    if degraded is not None and world > 1 and not (dd_engine or "").startswith("native"):
+        out["degraded"] = degraded     # the native decomposition (north_star's) did not produce this line
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pkg, args)
@@ -485,19 +611,19 @@ def main():
     if dd_engine is not None and dd_engine.startswith("native") and scaling == "strong" and target_cells > args.cells:
         target = {"cells": target_cells}
         # The headline measurement above is complete; this second box must not be able to lose it.  If the leg has not
-        # finished within --target-timeout seconds (a collective that never completes cannot be interrupted from inside),
-        # rank 0 prints the line with the leg marked as timed out and every rank leaves the process at once.
-        import threading
+        # finished within its limit (a collective that never completes cannot be interrupted from inside), rank 0 prints the
+        # line with the leg marked as timed out and every rank leaves the process at once.
+        line["out"] = out                                               # from here on the last-resort timer has a line to print
+        target_limit = min(float(args.target_timeout), budget.left() - 15.0)
         done = threading.Lock()
 
         def bail():
             if not done.acquire(blocking=False):
                 return
-            if rank == 0:
-                out["target_box"] = dict(target, error="timed out after %d s" % args.target_timeout)
-                print(json.dumps(out), flush=True)
+            out["target_box"] = dict(target, error="timed out after %.0f s" % max(target_limit, 0.0))
+            emit()
             os._exit(0)
-        watchdog = threading.Timer(args.target_timeout, bail)
+        watchdog = threading.Timer(max(target_limit, 0.0), bail)
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -541,8 +667,14 @@ def main():
         if not done.acquire(blocking=False):                        # the watchdog is printing: it also ends the process
             time.sleep(30)
         out["target_box"] = target
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        if "error" in target:
+            # this rank's leg failed: the others may be waiting in a collective it will never enter.  The line goes out and
+            # the process ends here, without a barrier nobody may reach (their own watchdogs end them, status 0)
+            line["out"] = out
+            emit()
+            os._exit(0)
+    line["out"] = out
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -129,6 +129,9 @@ struct BrickArgs {
     // list entries are tile slots shifted left by idx_shift: single-species boxes store BYTE offsets into the coordinate
     // planes (slot * sizeof(real); a tile of <= 2048 slots keeps them below 2^16), saving the address shift per pair
     int idx_shift;
+    // fp32 operator path only (BRICK_FORCE, record tile): the reference's own Float32 arithmetic -- the tile holds scaled
+    // positions s = x / L and every pair takes L (ds - round(ds)) (src/nonbonded.jl:40,52-61,70) instead of staged images
+    int refmath;
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -939,13 +942,33 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         }
     }
     // ---- stage the tile: HBM -> LDS, unit stride inside each tile row, image shift applied -----------
+    // fp32 boxes: the tile holds coordinates RELATIVE TO THE BRICK ORIGIN, worked out in fp64 with the +-L image shift folded
+    // into the origin (as k_brick_build does for fp64 boxes): one rounding at the ulp of a brick-sized number (<= 1e-6 sigma)
+    // instead of an addition of +-L to an absolute fp32 coordinate, whose result carries the ulp of [L, 2L) -- 1.5e-5 sigma in
+    // the 10^7-atom box, and the reason the O(N) path used to miss the reference's own fp32 bound (test/runtests.jl:39-41).
+    constexpr bool REL = sizeof(real) == 4;
+    const bool refmath = REL && MODE == BRICK_FORCE && !SOA && a.refmath != 0;
+    double org[3] = {0.0, 0.0, 0.0};
+    if (REL) {
+        org[0] = (double)a.g.lo[0] + (double)(bxi * Shape::BX) * ((double)a.g.len[0] / (double)a.g.M[0]);
+        org[1] = (double)a.g.lo[1] + (double)(byi * Shape::BY) * ((double)a.g.len[1] / (double)a.g.M[1]);
+        org[2] = (double)a.g.lo[2] + (double)(bzi * Shape::BZ) * ((double)a.g.len[2] / (double)a.g.M[2]);
+    }
     brick_for_each_slot(T, [&](int s, int tc) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         Rec<real> r = a.rec[gp];
-        r.x += (real)((sh & 3) - 1) * a.g.len[0];
-        r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
-        r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
+        if (refmath) {           // scaled positions, as the reference keeps them (src/nonbonded.jl:52-61,124)
+            r.x = r.x / a.g.len[0]; r.y = r.y / a.g.len[1]; r.z = r.z / a.g.len[2];
+        } else if (REL) {
+            r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
+            r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);
+            r.z = (real)(((double)r.z + (double)(((sh >> 4) & 3) - 1) * (double)a.g.len[2]) - org[2]);
+        } else {
+            r.x += (real)((sh & 3) - 1) * a.g.len[0];
+            r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
+            r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
+        }
         if (FAST) { r.x *= a.uni.inv_sigma; r.y *= a.uni.inv_sigma; r.z *= a.uni.inv_sigma; }
         if (SOA) { plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z; }
         else tile[s] = r;
@@ -953,7 +976,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     });
     if (tid == 0) {   // the sentinel record every unused row entry points at: fails r2 < rc2, never NaN
         Rec<real> far;
-        const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
+        // (reference arithmetic wraps every difference into the box: there the sentinel is NaN, which fails r2 < rc2 as well)
+        const real big = refmath ? (real)__builtin_nanf("") : (sizeof(real) == 8 ? (real)1e30 : (real)1e18);
         far.x = far.y = far.z = big; far.hs = 0;
         if (SOA) { plane[0] = big; plane[PITCH] = big; plane[2 * PITCH] = big; }
         else tile[0] = far;
@@ -1093,7 +1117,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                         zj = *reinterpret_cast<const real *>(pj + 2 * PLANE_BYTES);
                         hs_j = te_j = 0;
                     } else tile_load<real>(tile, tile_te, sj, xj, yj, zj, hs_j, te_j);
-                    const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
+                    real dx = xi - xj, dy = yi - yj, dz = zi - zj;
+                    if (REL && MODE == BRICK_FORCE && !SOA) {
+                        if (refmath) {   // r_ij = L minimum_image(s_i - s_j), src/nonbonded.jl:40,70
+                            dx = a.g.len[0] * (dx - rint(dx)); dy = a.g.len[1] * (dy - rint(dy)); dz = a.g.len[2] * (dz - rint(dz));
+                        }
+                    }
                     const real r2 = dx * dx + dy * dy + dz * dz;
                     if (MODE == BRICK_STATS) {
                         st_inside += (b0 + t * G + gl < m && r2 < a.model.rc2) ? 1ull : 0ull;
@@ -1169,7 +1198,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     vx = a.lgv_c1 * vx + nx; vy = a.lgv_c1 * vy + ny; vz = a.lgv_c1 * vz + nz;
                     a.vel_next[p] = vx; a.vel_next[a.pitch + p] = vy; a.vel_next[2 * a.pitch + p] = vz;
                     Rec<real> r = a.rec[p];                    // keeps the LJAtom fields bit for bit
-                    if (FAST) { r.x += a.dt * vx; r.y += a.dt * vy; r.z += a.dt * vz; }   // (the tile holds scaled coordinates)
+                    // (the tile holds scaled coordinates in the FAST kernels and brick-relative ones in fp32 boxes)
+                    if (FAST || REL) { r.x += a.dt * vx; r.y += a.dt * vy; r.z += a.dt * vz; }
                     else { r.x = xi + a.dt * vx; r.y = yi + a.dt * vy; r.z = zi + a.dt * vz; }
                     a.rec_next[p] = r;
                     const real ex = r.x - bx, ey = r.y - by, ez = r.z - bz;

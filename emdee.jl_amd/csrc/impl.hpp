@@ -73,6 +73,8 @@ struct NbrImpl : INbr {
         EMDEE_REQUIRE(n >= 0 && skin >= 0, EMDEE_ERR_INVALID, "nbr: need N >= 0 and skin >= 0");
         sys.ctx = c;
         sys.skin = skin;
+        // Float32 callers get the reference's Float32 pair geometry (EMDEE_F32_FAST=1: the MD loop's brick-relative tiles)
+        sys.refmath = sizeof(real) == 4 && !std::getenv("EMDEE_F32_FAST");
     }
 
     void compute(void *forces, void *energies, void *virials, const void *positions, double L, const emdee_lj_model &model,

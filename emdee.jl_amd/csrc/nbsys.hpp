@@ -303,6 +303,7 @@ struct NbSystem {
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
         a.idx_shift = idx_shift;
+        a.refmath = (sizeof(real) == 4 && refmath) ? 1 : 0;
         a.thr2 = (real)(0.25 * skin * skin);
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
@@ -317,7 +318,7 @@ struct NbSystem {
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
             // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
-            if (uniform_atoms && tile_cap <= SOA_SLOTS && idx_shift == PLANE_SHIFT) {
+            if (uniform_atoms && tile_cap <= SOA_SLOTS && idx_shift == PLANE_SHIFT && !(MODE == BRICK_FORCE && sizeof(real) == 4 && refmath)) {
                 launch_brick_kernel_impl<V, MODE, BM, true>();
                 return;
             }
@@ -659,6 +660,9 @@ struct NbSystem {
 
     // operator path: outputs of the next compute_forces go straight to these caller-order arrays (tiled kernels only)
     real *out_f = nullptr, *out_e = nullptr, *out_w = nullptr;
+    // fp32 operator path: pair geometry in the reference's own Float32 arithmetic (scaled positions, minimum image per
+    // pair; brick.hpp BrickArgs::refmath) -- what keeps compute_nonbonded! within the reference's 1e-4 of its CPU loop
+    bool refmath = false;
 
     void compute_forces(int bitmask, int phase = 0) {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");

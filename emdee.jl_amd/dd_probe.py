@@ -11,7 +11,11 @@ Protocol (stdin/stdout, text): rank 0 prints `ID <256 hex digits>` (the RCCL uni
 the process that will serve the bootstrap); the parent hands that line to every other rank's child on stdin.  Every
 child ends with `OK <n_global> <owned> <potential energy> <rebuilds> <kinetic energy>` and exit code 0, or a traceback and exit code 1.
 
-    python emdee.jl_amd/dd_probe.py --world 8 --rank 3 --device 3 [--cells 36] [--steps 24] [--precision f64]
+The child never outlives its purpose: it asks the kernel to kill it when the process that started it dies
+(PR_SET_PDEATHSIG), and a timer of its own ends it with status 3 after --timeout seconds whatever it is waiting for -- a
+child blocked in an RCCL wait whose rank has gone would otherwise hold the GPU and its memory for ever.
+
+    python emdee.jl_amd/dd_probe.py --world 8 --rank 3 --device 3 [--cells 36] [--steps 24] [--precision f64] [--timeout 120]
 """
 import argparse
 import os
@@ -35,7 +39,19 @@ def main():
     ap.add_argument("--in-process", action="store_true",
                     help="all --world domains in this one process (device copies instead of RCCL): the reference a "
                          "multi-process run of the same grid is compared with")
+    ap.add_argument("--timeout", type=float, default=300.0, help="seconds after which this process ends itself (status 3)")
     args = ap.parse_args()
+
+    import ctypes
+    import signal
+    import threading
+    try:                                    # die with the rank that started me (PR_SET_PDEATHSIG = 1)
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+    except (OSError, AttributeError):
+        pass
+    own_limit = threading.Timer(max(args.timeout, 1.0), lambda: os._exit(3))
+    own_limit.daemon = True
+    own_limit.start()
 
     sys.path.insert(0, ROOT)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
