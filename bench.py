@@ -334,7 +334,8 @@ def main():
             if line["printed"] or line["out"] is None:
                 return line["printed"]
             if rank == 0:
-                print(json.dumps(line["out"]), flush=True)
+                sys.stdout.write(json.dumps(line["out"]) + "\n")          # one write: the line cannot be cut in two
+                sys.stdout.flush()
             line["printed"] = True
             return True
 

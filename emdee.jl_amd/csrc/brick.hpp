@@ -132,6 +132,8 @@ struct BrickArgs {
     // fp32 operator path only (BRICK_FORCE, record tile): the reference's own Float32 arithmetic -- the tile holds scaled
     // positions s = x / L and every pair takes L (ds - round(ds)) (src/nonbonded.jl:40,52-61,70) instead of staged images
     int refmath;
+    const real *user_pos;      // ... read from the CALLER's array (3 x N, caller order): the engine's records hold positions wrapped
+                               // into the box, and x - L rounded to fp32 is not the number the reference divides by L
 };
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
@@ -270,6 +272,12 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         __syncthreads();
         tile_n = T.off[IMG];
         n_own = T.off[IMG + 1];
+        // (capacities may come from the plan of the previous rebuild: a brick that outgrew them is skipped and reported,
+        // the host plans afresh and builds again before any force launch)
+        if (tile_n > a.tile_cap || n_own > a.own_cap) {
+            if (tid == 0) atomicMax(&a.flags[2], max(tile_n, n_own));
+            return false;
+        }
         return n_own > 0;
     }
     int my_cnt = 0;
@@ -959,7 +967,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         const int sh = T.shift[tc];
         Rec<real> r = a.rec[gp];
         if (refmath) {           // scaled positions, as the reference keeps them (src/nonbonded.jl:52-61,124)
-            r.x = r.x / a.g.len[0]; r.y = r.y / a.g.len[1]; r.z = r.z / a.g.len[2];
+            const size_t i = (size_t)a.perm[gp];
+            r.x = a.user_pos[3 * i] / a.g.len[0]; r.y = a.user_pos[3 * i + 1] / a.g.len[1]; r.z = a.user_pos[3 * i + 2] / a.g.len[2];
         } else if (REL) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);

@@ -250,6 +250,19 @@ struct DdImpl : IDd {
     DdImpl(emdee_ctx *c, const double len[3], const int g[3], int rank_first_, int n_local_, const void *unique_id,
            const emdee_lj_model &m, double skin_)
         : user_ctx(c), skin(skin_), model(m), rank_first(rank_first_), n_local(n_local_) {
+        // (a constructor that throws runs no destructor: streams, events, pinned words and the communicator created so far
+        // are released here, e.g. when ncclCommInitRank fails because two ranks share a device)
+        try {
+            construct(len, g, unique_id);
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
+
+    void construct(const double len[3], const int g[3], const void *unique_id) {
+        emdee_ctx *c = user_ctx;
+        const emdee_lj_model &m = model;
         use_device(c);
         for (int d = 0; d < 3; d++) {
             L[d] = len[d]; grid[d] = g[d];
@@ -270,13 +283,16 @@ struct DdImpl : IDd {
         if (const char *e = std::getenv("EMDEE_DD_OVERLAP")) overlap = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_STREAMS")) two_streams = std::atoi(e) != 1;
         for (int l = 0; l < n_local; l++) {
-            auto d = std::make_unique<Domain<real>>();
+            dom.push_back(std::make_unique<Domain<real>>());   // registered first: release() sees whatever it gets below
+            Domain<real> *d = dom.back().get();
             d->geo.init(L, grid, halo, rank_first + l);
             if (use_rccl) {
                 d->ctx = c;
             } else {
                 d->ctx = new emdee_ctx(*c);
                 d->owns_ctx = true;
+                d->ctx->stream = nullptr;
+                d->ctx->host_flags = nullptr;
                 EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->ctx->stream, hipStreamNonBlocking));
                 EMDEE_HIP_CHECK(hipHostMalloc((void **)&d->ctx->host_flags, 16 * sizeof(int32_t), hipHostMallocDefault));
                 memset(d->ctx->host_flags, 0, 16 * sizeof(int32_t));
@@ -292,7 +308,6 @@ struct DdImpl : IDd {
             d->small.ensure(96);
             d->red.ensure(8);
             EMDEE_HIP_CHECK(hipMemsetAsync(d->words.ptr, 0, DD_WORDS * sizeof(int), d->stream()));
-            dom.push_back(std::move(d));
         }
         if (use_rccl) {
             RcclApi &api = RcclApi::get();
@@ -303,27 +318,32 @@ struct DdImpl : IDd {
         }
     }
 
-    ~DdImpl() override {
+    ~DdImpl() override { release(); }
+
+    // everything the constructor creates, in whatever state it got to (handles that were never created are null)
+    void release() {
         (void)hipSetDevice(user_ctx->device);
         for (auto &d : dom) {
-            (void)hipStreamSynchronize(d->stream());
-            (void)hipStreamSynchronize(d->comm);
-            (void)hipStreamSynchronize(d->side);
+            if (d->ctx && d->ctx->stream) (void)hipStreamSynchronize(d->stream());
+            if (d->comm) (void)hipStreamSynchronize(d->comm);
+            if (d->side) (void)hipStreamSynchronize(d->side);
         }
         if (comm) (void)RcclApi::get().CommDestroy(comm);
+        comm = nullptr;
         for (auto &d : dom) {
             d->md.reset();
-            (void)hipEventDestroy(d->ev_packed);
-            (void)hipEventDestroy(d->ev_done);
-            (void)hipEventDestroy(d->ev_bnd);
-            (void)hipStreamDestroy(d->comm);
-            (void)hipStreamDestroy(d->side);
-            if (d->owns_ctx) {
-                (void)hipStreamDestroy(d->ctx->stream);
-                (void)hipHostFree(d->ctx->host_flags);
+            if (d->ev_packed) (void)hipEventDestroy(d->ev_packed);
+            if (d->ev_done) (void)hipEventDestroy(d->ev_done);
+            if (d->ev_bnd) (void)hipEventDestroy(d->ev_bnd);
+            if (d->comm) (void)hipStreamDestroy(d->comm);
+            if (d->side) (void)hipStreamDestroy(d->side);
+            if (d->owns_ctx && d->ctx) {
+                if (d->ctx->stream) (void)hipStreamDestroy(d->ctx->stream);
+                if (d->ctx->host_flags) (void)hipHostFree(d->ctx->host_flags);
                 delete d->ctx;
             }
         }
+        dom.clear();
     }
 
     Domain<real> &local(int l) {
@@ -444,21 +464,32 @@ struct DdImpl : IDd {
     // One species everywhere, or not?  Every engine looked at its own atoms (owned + ghosts) during the load; agree once
     // over all domains, so that later loads -- atoms only change owner -- skip that scan and its read-back.
     void agree_on_species() {
+        // (a domain without atoms has no opinion -- and takes the others' constants, for the atoms it may receive later)
         auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (double)u; };
+        auto unbits = [](double b) { uint32_t u = (uint32_t)(b + 0.5); float f; memcpy(&f, &u, 4); return f; };
         std::vector<std::vector<double>> v;
-        for (auto &d : dom)
-            v.push_back({d->sys().uniform_atoms ? 1.0 : 0.0, bits(d->sys().uni_first.half_sigma), bits(d->sys().uni_first.twice_sqrt_eps)});
-        double sum[3];
-        allreduce_sum(v, 3, sum);
+        for (auto &d : dom) {
+            const bool has = d->sys().n_total > 0;
+            v.push_back({has ? 1.0 : 0.0, has && d->sys().uniform_atoms ? 1.0 : 0.0, has ? bits(d->sys().uni_first.half_sigma) : 0.0,
+                         has ? bits(d->sys().uni_first.twice_sqrt_eps) : 0.0});
+        }
+        double sum[4];
+        allreduce_sum(v, 4, sum);
+        const double voters = sum[0];
         std::vector<std::vector<double>> ok;
         for (auto &d : dom) {
-            const bool same = sum[0] == (double)world && sum[1] == world * bits(d->sys().uni_first.half_sigma) &&
-                              sum[2] == world * bits(d->sys().uni_first.twice_sqrt_eps);
+            const bool has = d->sys().n_total > 0;
+            const bool same = voters > 0 && sum[1] == voters &&
+                              (!has || (sum[2] == voters * bits(d->sys().uni_first.half_sigma) && sum[3] == voters * bits(d->sys().uni_first.twice_sqrt_eps)));
             ok.push_back({same ? 1.0 : 0.0});
         }
         double agreed = 0;
         allreduce_sum(ok, 1, &agreed);
-        for (auto &d : dom) d->sys().uniform_known = agreed == (double)world ? 1 : 0;
+        const bool uni = agreed == (double)world;
+        for (auto &d : dom) {
+            d->sys().uniform_known = uni ? 1 : 0;
+            if (uni) d->sys().set_uniform_constants(emdee_lj_atom{unbits(sum[2] / voters), unbits(sum[3] / voters)});
+        }
     }
 
     // stable partition of items 0..n-1 by mask bits into nbins bins.  partition_prepare sizes and clears the per-block
@@ -679,26 +710,26 @@ struct DdImpl : IDd {
             // Everything the engine queues meanwhile follows ctx->stream, which is pointed at that stream for the duration.
             const bool aside = overlap && two_streams;
             hipStream_t main_stream = d.ctx->stream;
-            if (aside) {
-                EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_packed, 0));   // all earlier work of this domain
-                EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_done, 0));     // the halo
-                d.ctx->stream = d.side;
-            }
-            const int nthreads = std::max(d.n_ghost, std::max(d.geo.npeers, 1));
-            hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_ghost, d.n_owned,
-                               d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
-            d.md->current_mask = 0;
-            try {
+            {
+                // (in RCCL mode d.ctx is the CALLER's context: whatever is thrown below, its stream is put back)
+                struct StreamSwap {
+                    emdee_ctx *ctx;
+                    hipStream_t keep;
+                    ~StreamSwap() { ctx->stream = keep; }
+                } swap_back{d.ctx, main_stream};
+                if (aside) {
+                    EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_packed, 0));   // all earlier work of this domain
+                    EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_done, 0));     // the halo
+                    d.ctx->stream = d.side;
+                }
+                const int nthreads = std::max(d.n_ghost, std::max(d.geo.npeers, 1));
+                hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_ghost, d.n_owned,
+                                   d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
+                d.md->current_mask = 0;
                 compute(d, overlap ? 2 : 0);
-            } catch (...) {
-                d.ctx->stream = main_stream;
-                throw;
+                if (aside) EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
             }
-            if (aside) {
-                EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
-                d.ctx->stream = main_stream;
-                EMDEE_HIP_CHECK(hipStreamWaitEvent(main_stream, d.ev_bnd, 0));   // the next step (and any read-back) sees both halves
-            }
+            if (aside) EMDEE_HIP_CHECK(hipStreamWaitEvent(main_stream, d.ev_bnd, 0));   // the next step (and any read-back) sees both halves
         }
     }
 
@@ -740,7 +771,9 @@ struct DdImpl : IDd {
         EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_step: call emdee_dd_load first");
         EMDEE_REQUIRE(nsteps >= 0 && dt >= 0 && rebuild_every >= 0, EMDEE_ERR_INVALID, "emdee_dd_step: negative argument");
         if (nsteps == 0) return;
-        const bool tiled = dom[0]->sys().brick_active;    // (the same kernels on every domain: same box class)
+        // Which kernels a domain steps with is ITS business and may change at any rebuild (brick_active: the densest tile of
+        // this domain fits LDS or not; an empty domain launches nothing): the batches, their exchanges and the guard words
+        // are the same for everybody, so the send/recv sequences of the ranks cannot drift apart.
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
             if (!(d.md->current_mask & EMDEE_FORCES)) EMDEE_REQUIRE(false, EMDEE_ERR_STATE, "emdee_dd_step: forces are not current");
@@ -756,7 +789,6 @@ struct DdImpl : IDd {
             // displacement trigger: queue what the previous interval between rebuilds says is safe, then one step at a
             // time until the request comes -- a cancelled step costs a halo exchange that nobody uses
             else B = std::max(1, std::min(B, last_interval > 0 ? last_interval - dom[0]->since_build - 1 : 2));
-            if (!tiled) B = 1;
             if (rebuild_every > 0 && dom[0]->since_build + 1 >= rebuild_every) {
                 // fixed cadence: rebuild at the current positions, then the un-fused equivalent of one inner step
                 redistribute(true);
@@ -772,18 +804,22 @@ struct DdImpl : IDd {
             }
             for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
             for (int j = 0; j < B; j++) {
-                if (tiled) {
-                    for (auto &pd : dom) pd->sys().prepare_noise(dt);   // (thermostat only) before the pack: both halves read it
-                    with_halo(j, j, [&](Domain<real> &d, int phase) {
+                for (auto &pd : dom)
+                    if (pd->sys().brick_active) pd->sys().prepare_noise(dt);   // (thermostat only) before the pack: both halves read it
+                with_halo(j, j, [&](Domain<real> &d, int phase) {
+                    if (d.sys().n_total == 0) return;                     // nothing to move; its words stay clear
+                    if (d.sys().brick_active) {
                         // interior bricks look at my own request only (their neighbours are all mine); boundary bricks
                         // at the OR of everybody's
                         const int *guard = (phase == 1) ? d.V(j) : d.G(j);
-                        d.sys().fused_step(dt, dt, phase, rebuild_every > 0 ? nullptr : guard, d.V(j + 1), false, true);
-                    });
-                } else {
-                    // direct kernels (no guard words): decide on the host before the force pass
-                    with_halo(j, j, [&](Domain<real> &, int) {});
-                }
+                        const bool launched = d.sys().fused_step(dt, dt, phase, rebuild_every > 0 ? nullptr : guard, d.V(j + 1), false, true);
+                        EMDEE_REQUIRE(launched, EMDEE_ERR_STATE, "emdee_dd_step: domain %d could not launch its step kernel", d.geo.rank);
+                    } else if (phase != 1) {
+                        // tiles too large for LDS (dense slab, long cutoff): the direct kernels, whole domain behind the halo,
+                        // under the same words
+                        d.sys().guarded_split_step(dt, dt, rebuild_every > 0 ? nullptr : d.G(j), d.V(j + 1));
+                    }
+                });
             }
             int g[DD_MAX_BATCH];
             int ran = B;
@@ -793,17 +829,16 @@ struct DdImpl : IDd {
                     if (g[j]) { ran = j; break; }
                 stat_cancelled += B - ran;
             }
-            if (!tiled && ran == 1) {
-                for (auto &pd : dom) {
-                    pd->md->forces(EMDEE_FORCES, 0);
-                    pd->sys().kick_drift(dt, dt, pd->V(1));
-                }
-            }
             for (auto &pd : dom) {
                 Domain<real> &d = *pd;
+                const bool tiled = d.sys().brick_active && d.sys().n_total > 0;
                 if (tiled && ((B - ran) & 1)) d.sys().swap_step_buffers();   // the cancelled launches did not advance the ping-pong
-                if (tiled && d.sys().lgv_on) d.sys().lgv_step -= (unsigned long long)(B - ran);
+                if (d.sys().lgv_on && d.sys().n_total > 0) d.sys().lgv_step -= (unsigned long long)(B - ran);
                 if (tiled && d.sys().profiling) d.sys().timers[T_STEP].dropped += (overlap ? 2 : 1) * (B - ran);
+                if (!tiled && d.sys().profiling && d.sys().n_total > 0) {
+                    d.sys().timers[T_FORCE].dropped += B - ran;
+                    d.sys().timers[T_KICK_DRIFT].dropped += B - ran;
+                }
                 d.since_build += ran;
                 d.md->current_mask = 0;
             }

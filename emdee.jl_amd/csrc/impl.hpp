@@ -102,7 +102,9 @@ struct NbrImpl : INbr {
         if (sys.brick_active) {
             // the tiled kernels write the caller's arrays themselves (owner lane, caller index from perm)
             sys.out_f = uf; sys.out_e = ue; sys.out_w = uw;
+            sys.ref_pos = pos;
             sys.compute_forces(bitmask);
+            sys.ref_pos = nullptr;
             sys.out_f = sys.out_e = sys.out_w = nullptr;
         } else {
             sys.compute_forces(bitmask);

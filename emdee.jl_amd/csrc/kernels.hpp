@@ -503,8 +503,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void k_lj_force_nbr(int n, int n_owned
                                                               const int *__restrict__ cnt, GridP<real> g,
                                                               LJModel<real> model, size_t pitch,
                                                               real *__restrict__ frc, real *__restrict__ en,
-                                                              real *__restrict__ vir) {
+                                                              real *__restrict__ vir, const int *__restrict__ guard = nullptr) {
     __shared__ real s_out[5][FORCE_ATOMS];
+    if (guard != nullptr && *guard != 0) return;   // a step queued behind a rebuild request (emdee_dd_step): leave no trace
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     // XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs
@@ -575,8 +576,12 @@ template <typename real>
 __global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__restrict__ perm, Rec<real> *__restrict__ rec,
                              real *__restrict__ vel, const real *__restrict__ frc, const real *__restrict__ inv_mass,
                              real c, real dt, const real *__restrict__ xb, real thr2, int *__restrict__ flag,
-                             const real *__restrict__ noise, real c1) {
+                             const real *__restrict__ noise, real c1, const int *__restrict__ guard = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (guard != nullptr && *guard != 0) {   // queued behind a rebuild request: do nothing and pass the request on
+        if (p == 0) *flag = 1;
+        return;
+    }
     if (p >= n) return;
     if (perm[p] >= n_owned) return;
     Rec<real> r = rec[p];

@@ -154,7 +154,7 @@ struct NbSystem {
     void set_box(const double lo_[3], const double len_[3], const int per_[3]) {
         bool same = true;
         for (int d = 0; d < 3; d++) same = same && lo[d] == lo_[d] && len[d] == len_[d] && per[d] == (per_[d] ? 1 : 0);
-        if (!same) sorted = has_list = false;
+        if (!same) sorted = has_list = plan_valid = false;
         for (int d = 0; d < 3; d++) {
             lo[d] = lo_[d]; len[d] = len_[d]; per[d] = per_[d] ? 1 : 0;
             EMDEE_REQUIRE(len[d] > 0.0 && std::isfinite(len[d]), EMDEE_ERR_INVALID, "box length must be positive");
@@ -165,7 +165,7 @@ struct NbSystem {
         EMDEE_REQUIRE(m.rc2 > 0 && m.rs2 >= 0 && m.rs2 < m.rc2 && std::isfinite(m.inv_delta2), EMDEE_ERR_INVALID,
                       "LennardJonesModel needs 0 <= switch < cutoff (Q10: switch == cutoff gives 1/0)");
         EMDEE_REQUIRE(skin_ >= 0.0, EMDEE_ERR_INVALID, "skin must be >= 0");
-        if (m.rc2 != model_d.rc2 || skin_ != skin) has_list = sorted = false;
+        if (m.rc2 != model_d.rc2 || skin_ != skin) has_list = sorted = plan_valid = false;
         model_d = m;
         model = make_model<real>(m);
         skin = skin_;
@@ -303,7 +303,8 @@ struct NbSystem {
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
         a.idx_shift = idx_shift;
-        a.refmath = (sizeof(real) == 4 && refmath) ? 1 : 0;
+        a.refmath = (sizeof(real) == 4 && refmath && ref_pos != nullptr) ? 1 : 0;
+        a.user_pos = ref_pos;
         a.thr2 = (real)(0.25 * skin * skin);
         a.trigger = step_trigger ? step_trigger : flags.ptr + 1;
         a.guard = step_guard;
@@ -318,7 +319,7 @@ struct NbSystem {
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
             // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
-            if (uniform_atoms && tile_cap <= SOA_SLOTS && idx_shift == PLANE_SHIFT && !(MODE == BRICK_FORCE && sizeof(real) == 4 && refmath)) {
+            if (uniform_atoms && tile_cap <= SOA_SLOTS && idx_shift == PLANE_SHIFT && !(MODE == BRICK_FORCE && sizeof(real) == 4 && refmath && ref_pos != nullptr)) {
                 launch_brick_kernel_impl<V, MODE, BM, true>();
                 return;
             }
@@ -356,10 +357,10 @@ struct NbSystem {
         else launch_brick_kernel<V, BRICK_FORCE, 7>();
     }
 
-    // brick decomposition + exact LDS tile capacity for the current cell populations; false if a
-    // tile cannot fit in LDS (then the direct kernels are used)
-    bool plan_bricks() {
-        bool ok = true;
+    // brick decomposition + LDS tile capacity for the current cell populations; false if a tile cannot fit in LDS (then
+    // the direct kernels are used).  Three parts: the brick grid (geometry only), the population maxima (one small kernel,
+    // results in flags[6..8]), and the sizes derived from them on the host.
+    void plan_geometry() {
         with_brick_variant(variant, [&](auto v) {
             using V = decltype(v);
             using S = typename V::Shape;
@@ -388,22 +389,49 @@ struct NbSystem {
             bgrid.bb_y = bgrid.ib_n[2] * (bgrid.nb[1] - bgrid.ib_n[1]) * bgrid.nb[0];
             bgrid.bb_count = bgrid.nbricks - bgrid.ib_count;
             bgrid.bb_per_xcd = (bgrid.bb_count + NXCD - 1) / NXCD;
+            row_block = EPL * V::G;
+        });
+    }
+    // flags[6] = largest tile, flags[7] = most own atoms of a brick, flags[8] = most atoms in three consecutive cells of a tile row
+    void launch_tile_max() {
+        with_brick_variant(variant, [&](auto v) {
+            using S = typename decltype(v)::Shape;
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 6, 0, 3 * sizeof(int), stream()));
             hipLaunchKernelGGL((k_brick_tile_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
                                grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], start(),
                                flags.ptr + 6);
-            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 6, flags.ptr + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
-            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
-            tile_cap = std::max(64, (ctx->host_flags[6] + 1 + 15) / 16 * 16);   // + 1: the sentinel record
-            own_cap = std::max(64, (ctx->host_flags[7] + 15) / 16 * 16);
+        });
+    }
+    // A plan is kept from one rebuild to the next (the populations barely change): capacities carry a few percent of
+    // headroom, and the maxima of the NEW populations are checked after the build, together with its overflow words.
+    static int with_headroom(int v) { return (v + v / 32 + 8 + 15) / 16 * 16; }
+    bool plan_sizes(int max_tile, int max_own, int max_span3) {
+        bool ok = true;
+        with_brick_variant(variant, [&](auto v) {
+            using V = decltype(v);
+            using S = typename V::Shape;
+            tile_cap = std::max(64, with_headroom(max_tile + 1));   // + 1: the sentinel record
+            // (the single-species kernels keep coordinate planes of SOA_SLOTS records: do not let the headroom alone push a tile past them)
+            if (max_tile + 1 <= SOA_SLOTS) tile_cap = std::min(tile_cap, SOA_SLOTS);
+            own_cap = std::max(64, with_headroom(max_own));
+            {   // ... nor cost a workgroup per CU in the build or force kernels: give headroom back 16 records at a time
+                const int exact = std::max(64, (max_tile + 1 + 15) / 16 * 16), st = stride > 0 ? stride : 128;
+                auto per_cu = [&](int tc) {
+                    const size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB), f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
+                    return (int)(LDS_LIMIT / std::max<size_t>(b, 1)) * 16 + (int)(LDS_LIMIT / std::max<size_t>(f, 1));
+                };
+                while (tile_cap > exact && per_cu(tile_cap) < per_cu(exact)) tile_cap -= 16;
+            }
+            plan_span3 = max_span3 + max_span3 / 16 + 2;
             if (std::getenv("EMDEE_DEBUG_PLAN"))
-                std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d, own_cap %d, max 3-cell span %d\n", bgrid.nb[0],
-                             bgrid.nb[1], bgrid.nb[2], tile_cap, own_cap, ctx->host_flags[8]);
-            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
+                std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d (max %d), own_cap %d (max %d), max 3-cell span %d\n", bgrid.nb[0],
+                             bgrid.nb[1], bgrid.nb[2], tile_cap, max_tile, own_cap, max_own, max_span3);
+            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && plan_span3 <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
             // crowded tile rows (long cutoffs): the same build with one 32-bit hit field per row
-            if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && ctx->host_flags[8] <= 32 * V::GB) build_alg = 5;
+            if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && plan_span3 <= 32 * V::GB) build_alg = 5;
+            if (build_alg == 1) plan_span3 = 1 << 30;               // the ballot build has no limit
+            else plan_span3 = (build_alg == 5 ? 32 : BUILD2_FIELD) * V::GB;   // what the chosen build can take
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
-            row_block = EPL * V::G;
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
             // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
             // cmax, so each is off by <= cmax 2^-24 after rounding; with |d| <= r_list per component the
@@ -419,6 +447,19 @@ struct NbSystem {
         });
         return ok;
     }
+    int plan_span3 = 0;                   // most atoms in three consecutive cells of a tile row the chosen build kernel can take
+    // do the maxima of the current populations (flags[6..8], read back) fit the plan in use?
+    bool plan_holds(const int32_t *maxima) const {
+        return maxima[0] + 1 <= tile_cap && maxima[1] <= own_cap && maxima[2] <= plan_span3;
+    }
+    // first plan of a state (or one that no longer holds): blocking read-back of the maxima
+    bool plan_bricks() {
+        plan_geometry();
+        launch_tile_max();
+        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 6, flags.ptr + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        return plan_sizes(ctx->host_flags[6], ctx->host_flags[7], ctx->host_flags[8]);
+    }
 
     // ---------------------------------------------------------------- neighbour list
     bool brick_active = false;
@@ -432,15 +473,12 @@ struct NbSystem {
         return ok;
     }
 
-    void build_list() {
+    // full planning with a blocking read-back: variant, capacities, build kernel, stride rounding, index encoding
+    bool plan_valid = false;
+    int plan_M[3] = {0, 0, 0}, plan_n = 0;
+    void make_plan() {
         const int n = n_total;
-        if (stride == 0) {
-            double vol = len[0] * len[1] * len[2];
-            double expect = n > 0 ? (4.0 / 3.0) * M_PI * rlist * rlist * rlist * (double)n / vol : 0.0;
-            stride = (int)((expect * 1.3 + 24.0) / 16.0 + 1.0) * 16;
-        }
         if (!variant_forced) variant = 0;
-        btab_valid = false;
         brick_active = (path == PATH_BRICK) && n > 0 && plan_bricks();
         // A tile too large for two workgroups of the default variant per CU (long cutoffs, dense boxes: rc = 3.5
         // sigma needs 135 KB) would leave 2 waves per SIMD: take the same bricks with 1024-thread workgroups
@@ -457,6 +495,38 @@ struct NbSystem {
         // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
         if (brick_active && !build_fits_lds()) brick_active = false;
         idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !std::getenv("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
+        plan_valid = brick_active;
+        plan_uniform = uniform_atoms;
+        plan_n = n;
+        for (int d = 0; d < 3; d++) plan_M[d] = grid.M[d];
+    }
+    bool plan_uniform = false;
+
+    void build_list() {
+        const int n = n_total;
+        if (stride == 0) {
+            double vol = len[0] * len[1] * len[2];
+            double expect = n > 0 ? (4.0 / 3.0) * M_PI * rlist * rlist * rlist * (double)n / vol : 0.0;
+            // first guess: 15 % above the mean row (a jittered lattice at rho* = 0.8, r_list = 2.8 has 73.6 +- 4, longest row 85; the
+            // melt 91): rounded up to whole lane-major blocks below, 96 entries there.  A longer row grows the stride and
+            // builds again.  (128 instead of 96 costs 2 % of the step: 33 % more bytes flushed per build, rows 256 B apart)
+            stride = (int)((expect * 1.15 + 8.0) / 16.0 + 1.0) * 16;
+            if (const char *e = std::getenv("EMDEE_STRIDE")) stride = std::max(16, std::atoi(e));   // tuning: first guess of the row stride
+        }
+        btab_valid = false;
+        // The plan of the previous build of this state (variant, capacities, build kernel) is kept when the cell grid is the
+        // same: the populations barely change between rebuilds, the capacities carry headroom, and the maxima of the new
+        // populations come back with the build's overflow words -- ONE blocking read-back per rebuild instead of two.
+        bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
+                    plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= n + n / 8 && n <= plan_n + plan_n / 8 &&
+                    plan_uniform == uniform_atoms;
+        if (kept) {
+            plan_geometry();
+            launch_tile_max();
+            brick_active = true;
+        } else {
+            make_plan();
+        }
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 3 * sizeof(int), stream()));
@@ -464,7 +534,7 @@ struct NbSystem {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
-                    if (attempt == 0 && !std::getenv("EMDEE_NO_BRICK_TABLES")) {
+                    if (!btab_valid && !std::getenv("EMDEE_NO_BRICK_TABLES")) {
                         // tables of every brick, once per rebuild; the build and every force launch copy them in
                         // (the image depends on the brick shape only: a small workgroup writes it)
                         constexpr int TT = V::Shape::NTC <= 128 ? 128 : 256;
@@ -502,9 +572,18 @@ struct NbSystem {
                                        0, stream(), n, n_owned, view(), perm.ptr, cell_sorted.ptr, start(), grid,
                                        (real)(rlist * rlist), nbr.ptr, stride, cnt.ptr, flags.ptr);
             }
-            // a build is rare (every ~10 steps): one blocking read-back of the overflow words
-            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+            // a build is rare (every ~7 steps): one blocking read-back -- the overflow words and, under a kept plan, the
+            // population maxima it has to hold for
+            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 9 * sizeof(int), hipMemcpyDeviceToHost, stream()));
             EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+            if (kept && (!plan_holds(ctx->host_flags + 6) || ctx->host_flags[2] != 0)) {
+                // the populations outgrew the kept plan (the kernels skipped the bricks concerned): plan afresh and build again
+                kept = false;
+                plan_valid = false;
+                btab_valid = false;
+                make_plan();
+                continue;
+            }
             EMDEE_REQUIRE(ctx->host_flags[2] == 0, EMDEE_ERR_OVERFLOW, "LDS tile overflow (%d records > %d)",
                           ctx->host_flags[2], tile_cap);
             int needed = ctx->host_flags[0];
@@ -515,12 +594,13 @@ struct NbSystem {
             }
             stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
             if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;
-            if (brick_active && !build_fits_lds()) { brick_active = false; idx_shift = 0; btab_valid = false; }
+            if (brick_active && !build_fits_lds()) { brick_active = false; idx_shift = 0; btab_valid = false; plan_valid = false; }
         }
         EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
     }
 
     // ---------------------------------------------------------------- forces
+    const int *direct_guard = nullptr;    // guarded_split_step: the direct kernels of a queued step look at this word first
     template <int BM>
     void launch_direct_force() {
         const int n = n_total;
@@ -528,7 +608,7 @@ struct NbSystem {
         int per_xcd = (nblocks + NXCD - 1) / NXCD;
         hipLaunchKernelGGL((k_lj_force_nbr<real, BM>), dim3(per_xcd * NXCD), dim3(FORCE_BLOCK), 0, stream(), n, n_owned,
                            per_xcd, view(), perm.ptr, nbr.ptr, stride, cnt.ptr, grid, model, pitch, frc.ptr, en.ptr,
-                           vir.ptr);
+                           vir.ptr, direct_guard);
     }
 
     int force_phase = 0;
@@ -557,12 +637,17 @@ struct NbSystem {
         uni_first = first;
         if (ctx->host_flags[5] == 0 && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
-            // the same fp operations as the per-pair path: (hs + hs)^2 and te * te in the kernel's type
-            const real sg = (real)first.half_sigma + (real)first.half_sigma;
-            uni_sigma = (double)sg;
-            uni_sigma2 = (double)(sg * sg);
-            uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
+            set_uniform_constants(first);
         }
+    }
+    // launch constants of the single-species kernels
+    void set_uniform_constants(const emdee_lj_atom &first) {
+        uni_first = first;
+        // the same fp operations as the per-pair path: (hs + hs)^2 and te * te in the kernel's type
+        const real sg = (real)first.half_sigma + (real)first.half_sigma;
+        uni_sigma = (double)sg;
+        uni_sigma2 = (double)(sg * sg);
+        uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
     }
 
     // ---------------------------------------------------------------- Langevin thermostat (optional)
@@ -663,6 +748,7 @@ struct NbSystem {
     // fp32 operator path: pair geometry in the reference's own Float32 arithmetic (scaled positions, minimum image per
     // pair; brick.hpp BrickArgs::refmath) -- what keeps compute_nonbonded! within the reference's 1e-4 of its CPU loop
     bool refmath = false;
+    const real *ref_pos = nullptr;        // the caller's positions of the current operator call (refmath tiles are staged from them)
 
     void compute_forces(int bitmask, int phase = 0) {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
@@ -687,7 +773,7 @@ struct NbSystem {
     }
 
     // ---------------------------------------------------------------- integrator
-    void kick_drift(double c, double dt, int *trigger = nullptr) {
+    void kick_drift(double c, double dt, int *trigger = nullptr, const int *guard = nullptr) {
         EMDEE_REQUIRE(sorted && with_vel, EMDEE_ERR_STATE, "no velocities loaded");
         if (n_total == 0) return;
         prepare_noise(dt);
@@ -695,8 +781,22 @@ struct NbSystem {
         real thr = (real)(0.5 * skin);
         hipLaunchKernelGGL((k_kick_drift<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
                            pitch, perm.ptr, rec.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c, (real)dt,
-                           xb.ptr, thr * thr, trigger ? trigger : flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1);
+                           xb.ptr, thr * thr, trigger ? trigger : flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1, guard);
         if (lgv_on) lgv_step++;
+    }
+
+    // One inner step of a domain whose tiles do not fit LDS (the direct kernels), obeying the same device words as
+    // fused_step: nothing happens if *guard is set (and *trigger is raised, passing the request on), otherwise force pass,
+    // full kick and drift in place, *trigger raised if an atom is now skin/2 away from its position at the last build.
+    // Keeps a decomposed run's message sequence independent of which kernels a domain uses (emdee_dd_step).
+    void guarded_split_step(double c, double dt, const int *guard, int *trigger) {
+        EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
+        EMDEE_REQUIRE(!brick_active, EMDEE_ERR_STATE, "guarded_split_step is the direct kernels' form of fused_step");
+        if (n_total == 0) return;
+        direct_guard = guard;
+        compute_forces(EMDEE_FORCES, 0);
+        direct_guard = nullptr;
+        kick_drift(c, dt, trigger, guard);
     }
 
     void kick(double c) {

@@ -2,7 +2,7 @@
 # include/emdee_hip.h.  Build-defined: the reference is single-GPU (SURVEY.md 8(b) table, 8(e)).  One Julia process
 # per GPU (Distributed.jl / MPI.jl workers); rank 0 generates the communicator id and the caller hands it to the
 # other ranks by its own means, e.g.   id = rank == 0 ? dd_unique_id() : nothing;  id = MPI.bcast(id, 0, comm).
-export DomainDecomposition, dd_unique_id, set_atoms!, load!, owned_state!
+export DomainDecomposition, dd_unique_id, set_atoms!, load!, owned_state!, set_overlap!
 
 mutable struct DomainDecomposition{T}
     handle::Ptr{Cvoid}

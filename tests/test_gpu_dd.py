@@ -203,6 +203,87 @@ def test_dd_box_with_interior_bricks(emdee, world):
     assert dd.stats()["rebuilds"] >= 3
 
 
+def _jittered_slab(rng, x0, x1, L, spacing, jitter):
+    nx, nyz = int(round((x1 - x0) / spacing)), int(L // spacing)
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(nyz), np.arange(nyz), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+    return np.array([x0, 0.0, 0.0]) + (g + 0.5) * spacing + rng.uniform(-jitter, jitter, size=g.shape)
+
+
+@pytest.mark.parametrize("langevin", [0, 1])
+def test_dd_domains_on_different_kernel_classes(emdee, oracle, langevin):
+    """ADVICE r2 (dd.hpp:743): which kernels a domain steps with is data-dependent.  Here domain 0 holds a slab of small
+    atoms at 4.6 per sigma^3 -- a tile of 96 cells would need ~300 KB of LDS, so its engine falls back to the direct
+    (global-gather) kernels -- while domain 1 holds a dilute fluid and runs the LDS-tiled ones.  Both must follow the same
+    batches of guarded steps (a domain that silently skipped its launches, or queued a different number of exchanges,
+    would give a wrong trajectory or a hang), and the trajectory must be the undivided oracle's."""
+    E = emdee
+    rng = np.random.default_rng(5)
+    L = 28.0
+    dense = _jittered_slab(rng, 1.0, 13.0, L, 0.6, 0.05)
+    dilute = _jittered_slab(rng, 15.0, 27.0, L, 1.12, 0.08)
+    pos = np.concatenate([dense, dilute])
+    N = pos.shape[0]
+    eps = np.ones(N)
+    sigma = np.concatenate([np.full(dense.shape[0], 0.4), np.ones(dilute.shape[0])])
+    vel = 1.5 * E.synthetic.raw_normals(np.arange(N), N)
+    vel -= vel.mean(axis=0)
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, 2, pos, vel, atoms, L, scatter=False)
+    if langevin:
+        dd.set_langevin_(*LANGEVIN)
+    for r in range(2):
+        dd.engine(r).profile_(True)
+    nsteps, dt = 40, 0.004                               # hot enough for several displacement-triggered rebuilds
+    dd.step_(17, dt, 0)
+    dd.step_(nsteps - 17, dt, 0)
+    # domain 0 never launched the fused brick kernel, domain 1 did: the two kernel classes really ran side by side
+    fused = [dd.engine(r).kernel_time("lj_force_nbr_fused_step")[1] for r in range(2)]
+    split = [dd.engine(r).kernel_time("verlet_kick_drift")[1] for r in range(2)]
+    assert fused[0] == 0 and split[0] >= nsteps - 2, (fused, split)
+    assert fused[1] >= nsteps - 8, (fused, split)
+    orc_atoms = oracle.lj_atoms(eps, sigma)
+    if langevin:
+        ref = oracle.verlet_langevin(pos, vel, L, oracle.model(RC, RS), orc_atoms, dt, nsteps, *LANGEVIN)
+    else:
+        ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), orc_atoms, dt, nsteps)
+    x, v, f = _gather(dd, 2, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(v - ref["v"]).max() < 1e-8
+    assert np.abs(f - ref["f"]).max() < 1e-6 * np.abs(ref["f"]).max()
+    e1 = dd.totals()
+    assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
+    assert dd.stats()["rebuilds"] >= 2
+    dd.close()
+
+
+def test_dd_with_an_empty_domain(emdee, oracle):
+    """All atoms in the left half of the box, none within a halo of the cut: domain 1 owns nothing and sees no ghost.  It
+    must still take part in every exchange of every batch, and the trajectory must be the oracle's."""
+    E = emdee
+    rng = np.random.default_rng(9)
+    L = 28.0
+    pos = _jittered_slab(rng, 3.0, 10.0, L, 1.12, 0.08)
+    N = pos.shape[0]
+    eps, sigma = np.ones(N), np.ones(N)
+    vel = E.synthetic.raw_normals(np.arange(N), N)
+    vel -= vel.mean(axis=0)
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    dd = _build(E, 2, pos, vel, atoms, L, scatter=True)
+    c = [dd.counts(r) for r in range(2)]
+    assert c[0]["n_owned"] == N and c[1]["n_owned"] == 0 and c[1]["n_ghost"] == 0
+    dd.step_(25, DT, 0)
+    ref = oracle.verlet(pos, vel, L, oracle.model(RC, RS), oracle.lj_atoms(eps, sigma), DT, 25)
+    x, v, f = _gather(dd, 2, N)
+    dx = x - ref["x"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(f - ref["f"]).max() < 1e-6 * np.abs(ref["f"]).max()
+    e1 = dd.totals()
+    assert e1[0] == pytest.approx(ref["epot"][-1], rel=1e-8) and e1[1] == pytest.approx(ref["ekin"][-1], rel=1e-8)
+    assert dd.stats()["rebuilds"] >= 2
+    dd.close()
+
+
 def test_rccl_binding_on_one_rank(emdee):
     """The RCCL transport cannot run between two ranks on a one-GPU box; what can be checked here is the run-time
     binding it rests on: librccl resolved with dlopen, ncclGetUniqueId / ncclCommInitRank (the 128-byte id by value),

@@ -85,8 +85,8 @@ def test_all_pairs_kernels_against_oracle(emdee, oracle, dev, lj_sample, golden,
             assert rel_err(f, g["forces_" + mode]) < REL64 and rel_err(e, g["energies_" + mode]) < REL64
             assert rel_err(w, g["virials_" + mode]) < REL64
         else:
-            assert np.abs(f - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
-            assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 2e-4
+            # the reference's own bound between its two Float32 implementations, absolute (test/runtests.jl:39-41)
+            assert np.abs(f - f0).max() < 1e-4 and np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 1e-4
 
 
 # ------------------------------------------------------------------------- device pair function
