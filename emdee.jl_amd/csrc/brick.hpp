@@ -43,7 +43,10 @@ enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2, BRICK_STEP = 3 };
 constexpr int EPL = 8;   // neighbour entries per lane per 16-byte load
 // entries the force kernels read of every row without looking at its length: the NPF prefetched blocks of 8 G entries
 // and the one after them (rows are sentinel-padded, so the row stride must hold them)
-constexpr int brick_min_stride(int G) { return (((EPL * G) >= 128 ? 1 : 2) + 1) * EPL * G; }
+// (1024-thread workgroups with 4 lanes per atom are the long-row variant -- rc = 3.5 sigma: 184 entries -- and prefetch five
+// 32-entry blocks: with two, every further block of a row is a dependent global load that four wavefronts per SIMD cannot hide)
+constexpr int brick_prefetch_blocks(int G, int THREADS) { return (EPL * G) >= 128 ? 1 : ((G == 4 && THREADS >= 1024) ? 5 : 2); }
+constexpr int brick_min_stride(int G, int THREADS) { return (brick_prefetch_blocks(G, THREADS) + 1) * EPL * G; }
 
 template <int BX_, int BY_, int BZ_>
 struct BrickShape {
@@ -102,6 +105,9 @@ struct BrickArgs {
     int *flags;                // [0] row overflow (max count), [2] tile overflow
     real rlist2;
     float margin;              // build: half-width of the fp32 rounding band around rlist2
+    // near/far build (ALG 23): tile coordinates are scaled by nf_scale = k so that k^2 (r_near^2 - r_list^2) = -2.0 exactly --
+    // the class of a candidate is then the top two bits of the float k^2 (d^2 - r_list^2): sign = listed, sign and |.| >= 2 = near
+    float nf_scale, nf_scale2;
     LJModel<real> model;
     size_t pitch;
     real *frc, *en, *vir;
@@ -448,9 +454,16 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         const int sh = T.shift[tc];
         const Rec<real> r = a.rec[gp];
         float4 q;
-        q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
-        q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
-        q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
+        if constexpr (ALG == 23) {   // (scaled in the box's own precision, one rounding to fp32 as before)
+            const real ks = (real)a.nf_scale;
+            q.x = (float)(((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]) * ks);
+            q.y = (float)(((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]) * ks);
+            q.z = (float)(((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]) * ks);
+        } else {
+            q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
+            q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
+            q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
+        }
         q.w = __int_as_float(gp);
         tile[s] = q;
     });
@@ -517,6 +530,189 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         return pass;
     };
     auto in_range = [&](const float4 &qi, int p, int c, int tcr) -> bool { return in_range_q(qi, tile[c], p, c, tcr); };
+    if constexpr (ALG == 23) {
+        // ---- ALG 13 with NEAR entries first --------------------------------------------------------------------------
+        // The force kernels run their 31-instruction pair body whenever ANY of the 64 lanes of a wavefront is inside the
+        // cutoff, and 29 % of a row are skin entries (r_c <= d < r_list when the list is built).  Rows are therefore
+        // written near entries first (d < r_near = r_c + delta), far entries behind them: the lanes of a wavefront walk
+        // their rows in step, so its last pair steps see far entries in every lane -- pairs that only come inside the
+        // cutoff if both atoms use up most of the skin -- fail the cutoff test wave-wide and skip the body.  The force
+        // kernels need no change (the cutoff test decides, as ever); only the ORDER of a row differs.
+        // The class of a candidate costs nothing: with the tile scaled by k, k^2 (r_near^2 - r_list^2) = -2.0, the top two
+        // bits of the float t = k^2 (d^2 - r_list^2) are {t < 0 : listed, |t| >= 2 : near}, and ONE v_alignbit_b32 shifts
+        // both into the lane's digit string (the two-instruction compare + add-with-carry of ALG 13 did one bit).
+        static_assert(G == 8 && sizeof(unsigned) == 4, "near/far build: 8 lanes per atom");
+        constexpr int NROWS = 9, LOG2G = 3;
+        constexpr bool BAND = sizeof(real) == 8;
+        float nrl2 = -rl2 * a.nf_scale2, margin_v = a.margin * a.nf_scale2;
+        asm volatile("" : "+v"(nrl2), "+v"(margin_v));
+        const int kshift = a.idx_shift + LOG2G;                  // digit j of a row is tile slot cb + (trips - 1 - j) G
+        for (int ob = 0; ob < n_own; ob += NGROUPS) {            // wave-uniform trip count
+            const int o = ob + gid;
+            const bool have = o < n_own;
+            const int2 info = have ? T.oinfo[o] : make_int2(0, 0);
+            const int ti = info.y & 0xffff, p = info.x, oc = info.y >> 20;
+            const bool act = have && ((info.y >> 16) & 1) != 0;   // ghosts own no row
+            const float4 qi = tile[ti];
+            unsigned short *row = a.nbr + (size_t)p * a.stride;
+            for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
+            const int2 *rt = rtab + (act ? oc : Shape::NOC) * 9;
+            int trips_of[NROWS];
+            {   // wave-uniform trip counts of the nine rows from one reduction (as ALG 13)
+                int cv = (int)((unsigned)(rt[min(gl, NROWS - 1)].y + G - 1) / (unsigned)G);
+                int c8 = (int)((unsigned)(rt[NROWS - 1].y + G - 1) / (unsigned)G);
+                cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+                c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
+                auto rows_max = [](int v) {
+                    auto q = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+                    v = max((int)q[0], (int)q[1]);
+                    q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+                    return max((int)q[0], (int)q[1]);
+                };
+                cv = rows_max(cv);
+                c8 = rows_max(c8);
+#pragma unroll
+                for (int r = 0; r < NROWS; r++)
+                    trips_of[r] = (r == NROWS - 1) ? __builtin_amdgcn_readlane(c8, 0) : __builtin_amdgcn_readlane(cv, r);
+            }
+            unsigned D[NROWS];                                   // two bits per candidate of my share of each tile row
+            int2 rv_next = rt[0];
+#pragma unroll
+            for (int r = 0; r < NROWS; r++) {
+                const int c0 = rv_next.x, span = rv_next.y;
+                if (r + 1 < NROWS) rv_next = rt[r + 1];
+                const int lim = (int)((unsigned)(span - gl + G - 1) >> LOG2G);   // my candidates: slots cb + k G, k < lim (may be <= 0)
+                const int cb = c0 + gl;
+                const int trips = trips_of[r];                    // <= 16 (host check: a tile row holds <= 16 G atoms)
+                unsigned bits = 0;
+                const float4 *cand = tile + cb;
+                auto dist = [&](const float4 &q) {
+                    const float dx = qi.x - q.x, dyy = qi.y - q.y, dzz = qi.z - q.z;
+                    float t = __builtin_fmaf(dx, dx, nrl2);
+                    t = __builtin_fmaf(dyy, dyy, t);
+                    return __builtin_fmaf(dzz, dzz, t);
+                };
+                // rounding band (fp64 boxes): decided with the exact fp64 records (a far entry if listed)
+                auto exact = [&](float &t, int gpj, int k) {
+                    if (__builtin_fabsf(t) <= margin_v && k < lim) {
+                        int kq = k;
+                        asm volatile("" : "+s"(kq));
+                        const int c = cb + kq * G;
+                        int occ = oc;
+                        asm volatile("" : "+v"(occ));
+                        const int tcr = occ % BX + TX * (((occ / BX) % BY + r % 3) + TY * (occ / (BX * BY) + r / 3));
+                        const int tc = tcr + (c >= T.off[tcr + 1] ? 1 : 0) + (c >= T.off[tcr + 2] ? 1 : 0);
+                        const int sh = T.shift[tc];
+                        const Rec<real> ri = a.rec[p], rj = a.rec[gpj];
+                        const real ex = ri.x - (rj.x + (real)((sh & 3) - 1) * a.g.len[0]);
+                        const real ey = ri.y - (rj.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]);
+                        const real ez = ri.z - (rj.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]);
+                        t = (ex * ex + ey * ey + ez * ez < a.rlist2) ? -1.f : 1.f;
+                    }
+                };
+                auto shift_in = [&](float t) { bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t), 30); };   // bits = bits << 2 | t >> 30
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int k = 0; k + 1 < trips; k += 2) {             // (reads past my share / the tile: harmless)
+                    float4 q[2];
+                    float t[2];
+                    q[0] = cand[k * G]; q[1] = cand[(k + 1) * G];
+                    if constexpr (!BAND) { asm volatile("" : : "v"(q[0].w)); asm volatile("" : : "v"(q[1].w)); }
+                    t[0] = dist(q[0]); t[1] = dist(q[1]);
+                    if constexpr (BAND) {
+                        const float tm = __builtin_fminf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1]));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tm <= margin_v) != 0, 0)) {
+                            exact(t[0], __float_as_int(q[0].w), k);
+                            exact(t[1], __float_as_int(q[1].w), k + 1);
+                        }
+                    }
+                    shift_in(t[0]); shift_in(t[1]);
+                }
+                if (trips & 1) {
+                    const float4 q = cand[(trips - 1) * G];
+                    if constexpr (!BAND) asm volatile("" : : "v"(q.w));
+                    float t = dist(q);
+                    if constexpr (BAND) {
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabsf(t) <= margin_v) != 0, 0))
+                            exact(t, __float_as_int(q.w), trips - 1);
+                    }
+                    shift_in(t);
+                }
+                // candidate k sits at digit trips - 1 - k: what lies past my share (k >= lim) is the low trips - lim digits
+                const int drop = 2 * (trips - max(lim, 0));
+                bits = drop >= 32 ? 0u : ((bits >> drop) << drop);
+                if (r == 4) {                                         // the atom itself (its cell is the middle one of row 4)
+                    const int d = ti - c0;
+                    if ((d & (G - 1)) == gl) bits &= ~(3u << (2 * (trips - 1 - (d >> LOG2G))));
+                }
+                D[r] = bits;
+            }
+            // ---- phase 2: near entries of all lanes first, far entries behind them --------------------------------------
+            int mineN = 0, mineH = 0;
+#pragma unroll
+            for (int r = 0; r < NROWS; r++) {
+                const unsigned H = (D[r] >> 1) & 0x55555555u;         // listed: the sign bit of t
+                mineH += __popc(H);
+                mineN += __popc(H & D[r]);                            // ... and |t| >= 2
+            }
+            const int mineF = mineH - mineN;
+            auto group_prefix = [&](int v) {
+                int t = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, true);
+                v += gl >= 1 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR2, 0xf, 0xf, true);
+                v += gl >= 2 ? t : 0;
+                t = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR4, 0xf, 0xf, true);
+                v += gl >= 4 ? t : 0;
+                return v;
+            };
+            const int inclN = group_prefix(mineN), inclF = group_prefix(mineF);
+            const int totalN = __shfl(inclN, lane | (G - 1));
+            unsigned short *epN = rowbuf + (unsigned)(inclN - mineN), *epF = rowbuf + (unsigned)(totalN + inclF - mineF);
+            unsigned short *const ep_last = rowbuf + (ustride - 1u);
+            rv_next = rt[0];
+#pragma unroll
+            for (int r = 0; r < NROWS; r++) {
+                const int c0 = rv_next.x;
+                if (r + 1 < NROWS) rv_next = rt[r + 1];
+                // digit j (bit 2 j of the masks below) is tile slot c0 + gl + (trips - 1 - j) G
+                int base = (c0 + gl + (trips_of[r] - 1) * G) << a.idx_shift;
+                asm volatile("" : "+v"(base));
+                const unsigned H = (D[r] >> 1) & 0x55555555u;
+                unsigned WN = H & D[r], WF = H & ~D[r];
+                while (WN) {
+                    const int b = __ffs((int)WN) - 1;                 // = 2 j
+                    WN &= WN - 1;
+                    asm volatile("" : "+v"(WN));
+                    *(epN < ep_last ? epN : ep_last) = (unsigned short)(base - (b << (kshift - 1)));
+                    epN++;
+                }
+                while (WF) {
+                    const int b = __ffs((int)WF) - 1;
+                    WF &= WF - 1;
+                    asm volatile("" : "+v"(WF));
+                    *(epF < ep_last ? epF : ep_last) = (unsigned short)(base - (b << (kshift - 1)));
+                    epF++;
+                }
+            }
+            if (have) {
+                constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
+                for (int c = gl * EPL; c < a.stride; c += G * EPL) {
+                    const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7
+                    uint4 q;
+                    q.x = (unsigned)src[0 * GL] | ((unsigned)src[1 * GL] << 16);
+                    q.y = (unsigned)src[2 * GL] | ((unsigned)src[3 * GL] << 16);
+                    q.z = (unsigned)src[4 * GL] | ((unsigned)src[5 * GL] << 16);
+                    q.w = (unsigned)src[6 * GL] | ((unsigned)src[7 * GL] << 16);
+                    *reinterpret_cast<uint4 *>(row + c) = q;
+                }
+                if (gl == G - 1) {                            // the last lane's inclusive prefixes add up to the row length
+                    const unsigned total = (unsigned)(inclN + inclF);
+                    a.cnt[p] = act ? (int)min(total, ustride) : 0;
+                    if (total > ustride) atomicMax(&a.flags[0], (int)total);
+                }
+            }
+        }
+        return;
+    }
     if constexpr (ALG % 10 == 3 || ALG % 10 == 5) {   // ALG 13 / 15: the same with candidates dealt round-robin (below)
         // ALG 2 with a leaner candidate loop (the build is VALU-issue bound: 2.7 G wave-instructions per rebuild at
         // 10^7 atoms, profiles/r02): the trip count of a tile row is made WAVE-uniform (the longest chunk in the
@@ -655,9 +851,17 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 };
                 // the hit bit enters through the carry: bits = 2 bits + (t < -margin)
                 // (fp32 boxes, margin 0: the sign of the fused sum IS the definition of the listed set)
+                // (round 3: ONE instruction.  A candidate whose |t| is inside the margin has been settled by exact(), which
+                // leaves t = -1 or +1; for every other candidate t < -margin is t < 0; and t = d^2 - r_list^2 is never -0.
+                // So "listed" is the sign bit of t, and v_alignbit_b32 {bits, t} >> 31 is bits = 2 bits + sign(t) --
+                // what the compare + add-with-carry pair did in two: -6 % instructions in the candidate loop.)
                 auto shift_in = [&](float t) {
+#ifdef EMDEE_BUILD_CMP_ADDC
                     asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
                                  : "+v"(bits) : "v"(t), "v"(nmargin_v) : "vcc");
+#else
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t), 31);
+#endif
                 };
                 // UNR candidates per trip, loaded at its top: with six wavefronts per SIMD the LDS latency hides behind the
                 // other waves' arithmetic, and nothing is carried from trip to trip (no register rotation).  The band test
@@ -1022,7 +1226,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     int st_max = 0;
     // The first NPF blocks of a row are prefetched one atom ahead (G = 4: 64 of the ~72 entries of an LJ row; the
     // block after them is requested when the atom's turn starts and arrives while those 64 are being worked on).
-    constexpr int NPF = (BLK >= 128) ? 1 : 2;   // (G = 4: 64 entries ahead, the rest of the row one block ahead)
+    constexpr int NPF = brick_prefetch_blocks(G, THREADS);   // (G = 4: 64 entries ahead, the rest of the row one block ahead)
     struct IdxBuf { uint4 q[NPF]; };
     // (a group past the brick's last atom reads the last atom's row: valid memory, no zero-fill and no branch; its own
     // position is the sentinel record, so nothing it reads passes the cutoff test, and nothing it computes is stored)

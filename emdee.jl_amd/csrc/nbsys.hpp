@@ -57,7 +57,9 @@ template <> struct BrickVariant<3> { using Shape = BrickShape<4, 2, 2>; static c
 template <> struct BrickVariant<4> { using Shape = BrickShape<6, 2, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
 template <> struct BrickVariant<5> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 256, G = 8, GB = G; };
 template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static constexpr int THREADS = 512, G = 8, GB = G; };
-template <> struct BrickVariant<7> { using Shape = BrickShape<5, 2, 2>; static constexpr int THREADS = 768, G = 8, GB = G; };
+// (7: the 1024-thread workgroup of variant 8 with FOUR lanes per atom: long rows, e.g. the rc = 3.5 sigma mixture -- 184 entries
+// are 46 pair steps per lane -- amortise a round's fixed work over 16 atoms per wavefront instead of 8)
+template <> struct BrickVariant<7> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 4, GB = 8; };
 template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8, GB = G; };
 
 template <class F>
@@ -295,6 +297,11 @@ struct NbSystem {
         a.g = grid; a.bg = bgrid; a.tile_cap = tile_cap; a.own_cap = own_cap;
         a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
         a.rlist2 = (real)(rlist * rlist); a.margin = build_margin; a.model = model; a.pitch = pitch;
+        {
+            const double k = near_far_scale();
+            a.nf_scale = k > 0.0 ? (float)k : 1.f;
+            a.nf_scale2 = a.nf_scale * a.nf_scale;     // (the square of the fp32 scale the tile really gets)
+        }
         if (const char *dbg = std::getenv("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
@@ -464,6 +471,21 @@ struct NbSystem {
     // ---------------------------------------------------------------- neighbour list
     bool brick_active = false;
 
+    // near/far rows (EMDEE_BUILD_NEARFAR=1; measured in round 3 and left OFF: the force launch gains 6 %, 1.280 -> 1.199 ms,
+    // the build loses 0.6 ms, 2.92 -> 3.52, because nine rows x two classes make 18 short emission loops that each run as
+    // long as the busiest lane of the wavefront -- 585 vs 584 steps/s; profiles/README.md):
+    // r_near = r_c + delta (EMDEE_NEAR_DELTA, default 0.04 length units); returns the scale k of the build tile with
+    // k^2 (r_list^2 - r_near^2) = 2, or 0 when switched off or the skin is too thin
+    double near_far_scale() const {
+        const char *on = std::getenv("EMDEE_BUILD_NEARFAR");
+        if (on == nullptr || std::atoi(on) == 0) return 0.0;
+        double delta = 0.04;
+        if (const char *e = std::getenv("EMDEE_NEAR_DELTA")) delta = std::atof(e);
+        const double rc = std::sqrt((double)model_d.rc2), rn = rc + delta;
+        if (!(delta >= 0.0) || rn >= rlist - 0.05 * skin) return 0.0;
+        return std::sqrt(2.0 / (rlist * rlist - rn * rn));
+    }
+
     bool build_fits_lds() {
         bool ok = true;
         with_brick_variant(variant, [&](auto v) {
@@ -489,7 +511,7 @@ struct NbSystem {
         }
         if (brick_active) {
             stride = (stride + row_block - 1) / row_block * row_block;   // whole lane-major blocks
-            with_brick_variant(variant, [&](auto v) { stride = std::max(stride, brick_min_stride(decltype(v)::G)); });
+            with_brick_variant(variant, [&](auto v) { stride = std::max(stride, brick_min_stride(decltype(v)::G, decltype(v)::THREADS)); });
         }
         // the build kernel's LDS (fp32 tile + tables + one row buffer per lane group) must fit as well: very dense or
         // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
@@ -554,9 +576,13 @@ struct NbSystem {
                         if (build_alg == 3) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 3, V::G>;
                         if (build_alg == 5) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 5, V::G>;
                         // round-robin candidates (brick.hpp): when the force kernels read plane values or 16-byte records with 4 lanes per atom
-                        if constexpr (V::G == 4) {
-                            const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !std::getenv("EMDEE_BUILD_CHUNKED");
+                        if constexpr (V::G == 4 || (V::G == 8 && sizeof(real) == 4)) {
+                            // (8 lanes per atom on 16-byte records: EMDEE_BUILD_STRIDED=1 only, an experiment)
+                            const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !std::getenv("EMDEE_BUILD_CHUNKED") &&
+                                                    (V::G == 4 || std::getenv("EMDEE_BUILD_STRIDED") != nullptr);
                             if (build_alg == 3 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 13, V::G>;
+                            // ... and near entries first (brick.hpp ALG 23), when the skin leaves room for a near radius
+                            if (build_alg == 3 && strided_ok && near_far_scale() > 0.0) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 23, V::G>;
                             if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
                         }
                     }
