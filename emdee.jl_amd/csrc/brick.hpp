@@ -403,6 +403,22 @@ __global__ __launch_bounds__(THREADS) void k_brick_tables(BrickArgs<real> a) {
     int *row = a.btab + (size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * ROW;
     for (int i = threadIdx.x; i < IMG; i += THREADS) row[i] = T.off[i];
     if (threadIdx.x == 0) { row[IMG] = tile_n; row[IMG + 1] = n_own; }
+    // The population maxima a kept plan is checked against (NbSystem::plan_holds), as k_brick_tile_max reports them:
+    // flags[6] largest tile, [7] most own atoms, [8] most atoms in three consecutive cells of a tile row.
+    if (a.stats != nullptr) {
+        int span3 = 0;
+        if (threadIdx.x < Shape::NTC && threadIdx.x % Shape::TX + 3 <= Shape::TX) span3 = T.off[threadIdx.x + 3] - T.off[threadIdx.x];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) span3 = max(span3, __shfl_xor(span3, off));
+        // (same-address atomics serialise in L2 at ~10 ns each and there is one workgroup per brick: look first (a device-scope load: the per-CU cache would
+        // keep showing the zero it saw first), and only the few bricks that raise a maximum pay for an atomic -- without the look this kernel took 1.6 ms instead of 0.04)
+        int *maxima = reinterpret_cast<int *>(a.stats);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && span3 > __hip_atomic_load(&maxima[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxima[2], span3);
+        if (threadIdx.x == 0) {
+            if (tile_n - 1 > __hip_atomic_load(&maxima[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxima[0], tile_n - 1);
+            if (n_own > __hip_atomic_load(&maxima[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxima[1], n_own);
+        }
+    }
 }
 
 constexpr int OWN_REGS = 2;   // own atoms per thread whose table entry is fetched before the tile is staged

@@ -554,6 +554,17 @@ struct DdImpl : IDd {
             explicit Scope(bool &b) : f(b) { f = true; }
             ~Scope() { f = false; }
         } scope(in_rebuild);
+        if (world == 1 && from_engines) {
+            // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
+            // none of the ownership passes and their two count read-backs)
+            Domain<real> &d = *dom[0];
+            d.md->rebuild();
+            d.md->forces(EMDEE_FORCES, 0);
+            d.since_build = 0;
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            stat_rebuilds++;
+            return;
+        }
         // ---- 0. caller-order copies of the integrated state
         for (auto &pd : dom) {
             Domain<real> &d = *pd;

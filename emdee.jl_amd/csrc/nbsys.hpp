@@ -423,9 +423,11 @@ struct NbSystem {
             own_cap = std::max(64, with_headroom(max_own));
             {   // ... nor cost a workgroup per CU in the build or force kernels: give headroom back 16 records at a time
                 const int exact = std::max(64, (max_tile + 1 + 15) / 16 * 16), st = stride > 0 ? stride : 128;
+                // (a CU holds three workgroups only up to ~50,000 B each, not 160 KB / 3: measured in round 2 by padding the launch)
+                constexpr size_t USABLE = 150000;
                 auto per_cu = [&](int tc) {
                     const size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB), f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
-                    return (int)(LDS_LIMIT / std::max<size_t>(b, 1)) * 16 + (int)(LDS_LIMIT / std::max<size_t>(f, 1));
+                    return (int)(USABLE / std::max<size_t>(b, 1)) * 16 + (int)(USABLE / std::max<size_t>(f, 1));
                 };
                 while (tile_cap > exact && per_cu(tile_cap) < per_cu(exact)) tile_cap -= 16;
             }
@@ -523,6 +525,7 @@ struct NbSystem {
         for (int d = 0; d < 3; d++) plan_M[d] = grid.M[d];
     }
     bool plan_uniform = false;
+    bool maxima_from_tables = std::getenv("EMDEE_PLAN_MAXIMA") != nullptr && std::string(std::getenv("EMDEE_PLAN_MAXIMA")) == "tables";
 
     void build_list() {
         const int n = n_total;
@@ -539,12 +542,17 @@ struct NbSystem {
         // The plan of the previous build of this state (variant, capacities, build kernel) is kept when the cell grid is the
         // same: the populations barely change between rebuilds, the capacities carry headroom, and the maxima of the new
         // populations come back with the build's overflow words -- ONE blocking read-back per rebuild instead of two.
-        bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
+        bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && !std::getenv("EMDEE_NO_BRICK_TABLES") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
                     plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= n + n / 8 && n <= plan_n + plan_n / 8 &&
                     plan_uniform == uniform_atoms;
         if (kept) {
             plan_geometry();
-            launch_tile_max();
+            // (taking the maxima from k_brick_tables instead, which has every brick's tables in LDS anyway, was measured and
+            // lost: one workgroup per brick means one look at -- or atomic on -- three hot words per brick, 2.84 -> 2.95 ms per
+            // rebuild even with a device-scope look before the atomic, 4.50 ms without; k_brick_tile_max reduces 64 bricks per
+            // wavefront first.  EMDEE_PLAN_MAXIMA=tables switches it on)
+            if (maxima_from_tables) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 6, 0, 3 * sizeof(int), stream()));
+            else launch_tile_max();
             brick_active = true;
         } else {
             make_plan();
@@ -566,6 +574,7 @@ struct NbSystem {
                         btab_valid = false;
                         BrickArgs<real> ta = brick_args();
                         ta.btab = btab.ptr;
+                        ta.stats = (kept && maxima_from_tables) ? reinterpret_cast<unsigned long long *>(flags.ptr + 6) : nullptr;
                         hipLaunchKernelGGL((k_brick_tables<real, typename V::Shape, TT>), dim3(bgrid.per_xcd * NXCD), dim3(TT),
                                            BT::bytes(0), stream(), ta);
                         btab_valid = true;

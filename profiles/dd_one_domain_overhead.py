@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 E = load_package()
 dev = torch.device("cuda", 0)
-cells = int(sys.argv[1]) if len(sys.argv) > 1 else 86
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 68          # 68^3 x 4 = 1,257,728 atoms: a rank of the 8-GPU 10^7-atom run
 model = E.LennardJonesModel(2.5, 2.0)
 skin = float(os.environ.get("SKIN", "0.3"))
 dd = E.DomainDecomposition.synthetic(cells, 1, None, dev, model, skin=skin, pkg=E)

@@ -65,6 +65,7 @@ def test_two_ranks_on_one_gpu_fall_back_to_the_torch_driver():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 12 ** 3
     assert d["config"]["decomposition"].startswith("torch"), d["config"]
     assert d["config"]["decomposition_probe"].startswith("failed"), d["config"]
+    assert "probe" in d.get("degraded", ""), d.get("degraded")      # the line says that, and why, the native decomposition did not produce it
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
     assert d["energy_per_atom"]["kinetic"] > 0.5
 
@@ -79,6 +80,7 @@ def test_two_ranks_over_rccl_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["atoms"] == 4 * 16 ** 3
     assert d["config"]["decomposition"].startswith("native") and "RCCL" in d["config"]["decomposition"], d["config"]
     assert d["config"]["decomposition_probe"].startswith("OK "), d["config"]
+    assert "degraded" not in d
     h = d["config"]["halo_exchange"]                               # both forms of the step were tried before the timed run
     assert h["chosen"] in ("overlapped", "in order") and set(h["trial_ms_per_step"]) == {"overlapped", "in order"}
     t = d["target_box"]
