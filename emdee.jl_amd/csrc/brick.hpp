@@ -138,6 +138,9 @@ struct BrickArgs {
     // fp32 operator path only (BRICK_FORCE, record tile): the reference's own Float32 arithmetic -- the tile holds scaled
     // positions s = x / L and every pair takes L (ds - round(ds)) (src/nonbonded.jl:40,52-61,70) instead of staged images
     int refmath;
+    // typed boxes (two species, typed.hpp): per-(cell, species) starts and the pair constants sigma_ij^2, 4 eps_ij, [ti * 2 + tj]
+    const int *tstart;
+    real tsig2[4], te4[4];
     const real *user_pos;      // ... read from the CALLER's array (3 x N, caller order): the engine's records hold positions wrapped
                                // into the box, and x - L rounded to fp32 is not the number the reference divides by L
 };
@@ -225,15 +228,10 @@ __device__ __forceinline__ int pick16(const uint4 &q, int t) {   // t is a compi
     return (int)((t & 1) ? (w >> 16) : (w & 0xffffu));
 }
 
-// Fills the tile-cell and own-cell tables of this block's brick.  Returns false when the block
-// has nothing to do.  Contains block barriers: every thread of the block must call it.
-template <typename real, class Shape, int THREADS, bool COMPUTE = false>
-__device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const BrickTables<Shape, THREADS> &T, int &bxi,
-                                            int &byi, int &bzi, int &tile_n, int &n_own) {
-    constexpr int BX = Shape::BX, BY = Shape::BY, BZ = Shape::BZ, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC,
-                  NOC = Shape::NOC;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int Mx = a.g.M[0], My = a.g.M[1], Mz = a.g.M[2];
+// Which brick does this workgroup own?  (phase 0: every brick, XCD-contiguous; 1: the interior sub-box; 2: the boundary
+// shell.)  False if the block is past the end of its enumeration.
+template <typename real>
+__device__ __forceinline__ bool brick_of_block(const BrickArgs<real> &a, int &bxi, int &byi, int &bzi) {
     if (a.phase == 1) {
         // interior bricks only, enumerated densely: the grid is ib_per_xcd * 8 blocks
         const int li = (blockIdx.x % NXCD) * a.bg.ib_per_xcd + blockIdx.x / NXCD;
@@ -267,7 +265,19 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         if (lb >= a.bg.nbricks) return false;
         bxi = lb % a.bg.nb[0]; byi = (lb / a.bg.nb[0]) % a.bg.nb[1]; bzi = lb / (a.bg.nb[0] * a.bg.nb[1]);
     }
+    return true;
+}
 
+// Fills the tile-cell and own-cell tables of this block's brick.  Returns false when the block
+// has nothing to do.  Contains block barriers: every thread of the block must call it.
+template <typename real, class Shape, int THREADS, bool COMPUTE = false>
+__device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const BrickTables<Shape, THREADS> &T, int &bxi,
+                                            int &byi, int &bzi, int &tile_n, int &n_own) {
+    constexpr int BX = Shape::BX, BY = Shape::BY, BZ = Shape::BZ, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC,
+                  NOC = Shape::NOC;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int Mx = a.g.M[0], My = a.g.M[1], Mz = a.g.M[2];
+    if (!brick_of_block(a, bxi, byi, bzi)) return false;
     if (!COMPUTE && a.btab != nullptr) {
         // the tables of this brick were computed when the list was built (the cell populations are frozen until the
         // next rebuild): copy the image instead of redoing the scans and the serial own-cell prefix in every launch
@@ -1193,12 +1203,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);
             r.z = (real)(((double)r.z + (double)(((sh >> 4) & 3) - 1) * (double)a.g.len[2]) - org[2]);
-        } else {
+        } else if (sh != (1 | (1 << 2) | (1 << 4))) {   // (only tiles at a periodic face hold shifted cells: the rest skips the decode)
             r.x += (real)((sh & 3) - 1) * a.g.len[0];
             r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
             r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
         }
-        if (FAST) { r.x *= a.uni.inv_sigma; r.y *= a.uni.inv_sigma; r.z *= a.uni.inv_sigma; }
+        if (FAST && a.uni.inv_sigma != (real)1) { r.x *= a.uni.inv_sigma; r.y *= a.uni.inv_sigma; r.z *= a.uni.inv_sigma; }
         if (SOA) { plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z; }
         else tile[s] = r;
         if (sizeof(real) == 4 && !SOA) tile_te[s] = a.te[gp];

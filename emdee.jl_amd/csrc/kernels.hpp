@@ -106,6 +106,76 @@ struct RecPos {
     }
 };
 
+// ------------------------------------------------------------------------------------ species ("typed" boxes)
+// A box with 2 distinct LJAtom values is sorted by (cell, species): inside a cell the atoms of species 0 come first.
+// The LDS tiles of the brick kernels are then staged species-major, neighbour rows come out as one segment per neighbour
+// species, and the pair loop needs no per-pair parameter mixing (brick.hpp, NT).  The table holds the distinct LJAtom
+// bit patterns in ascending order (the host sorts what k_species_collect found: the numbering must not depend on a race).
+constexpr int MAX_SPECIES = 4;
+struct SpeciesTable {
+    int n;                                  // 1: untyped (every kernel behaves as before)
+    unsigned long long key[MAX_SPECIES];    // half_sigma bits | twice_sqrt_eps bits << 32
+};
+__host__ __device__ __forceinline__ unsigned long long species_key(float hs, float te) {
+    unsigned a, b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    a = __float_as_uint(hs); b = __float_as_uint(te);
+#else
+    memcpy(&a, &hs, 4); memcpy(&b, &te, 4);
+#endif
+    return (unsigned long long)a | ((unsigned long long)b << 32);
+}
+__device__ __forceinline__ int species_of(const SpeciesTable &t, unsigned long long k) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_SPECIES; q++) s = (q < t.n && t.key[q] == k) ? q : s;
+    return s;
+}
+// species of item i of a position source (caller order: from the LJAtom array; cell order: from the records)
+struct NoSpecies {
+    __device__ __forceinline__ int of(int) const { return 0; }
+};
+struct UserSpecies {
+    SpeciesTable t;
+    const emdee_lj_atom *atoms;
+    __device__ __forceinline__ int of(int i) const { return species_of(t, species_key(atoms[i].half_sigma, atoms[i].twice_sqrt_eps)); }
+};
+template <typename real>
+struct RecSpecies;
+template <>
+struct RecSpecies<double> {
+    SpeciesTable t;
+    const Rec<double> *rec;
+    const float *te;
+    __device__ __forceinline__ int of(int i) const { return species_of(t, species_key(rec[i].hs, rec[i].te)); }
+};
+template <>
+struct RecSpecies<float> {
+    SpeciesTable t;
+    const Rec<float> *rec;
+    const float *te;
+    __device__ __forceinline__ int of(int i) const { return species_of(t, species_key(rec[i].hs, te[i])); }
+};
+// distinct LJAtom values of a box, at most MAX_SPECIES: tab[0..3] = keys in order of arrival (EMPTY = all ones),
+// tab[4] != 0 if there are more.  Almost every thread finds its key with device-scope loads; the atomics are for the
+// first few arrivals.
+static __global__ void k_species_collect(int n, const emdee_lj_atom *__restrict__ atoms, unsigned long long *__restrict__ tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long mine = species_key(atoms[i].half_sigma, atoms[i].twice_sqrt_eps), EMPTY = ~0ull;
+    for (int q = 0; q < MAX_SPECIES; q++) {
+        unsigned long long cur = __hip_atomic_load(&tab[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY) cur = atomicCAS(&tab[q], EMPTY, mine);
+        if (cur == EMPTY || cur == mine) return;
+    }
+    tab[MAX_SPECIES] = 1;
+}
+// cstart[c] = first slot of cell c, from the per-(cell, species) starts of a typed sort
+static __global__ void k_cell_starts(int ncell, int nt, const int *__restrict__ tstart, int *__restrict__ cstart) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= ncell) cstart[c] = tstart[(size_t)c * nt];
+}
+
 // ------------------------------------------------------------------------------------ binning
 // Runs of equal keys among the 64 lanes of a wavefront (adjacent lanes only).  When the input is already
 // nearly cell-ordered -- every MD rebuild -- a wavefront spans ~4 cells, so one atomic per RUN instead of one
@@ -121,14 +191,16 @@ __device__ __forceinline__ void wave_run(int key, int &first, int &len) {
 }
 
 // Radix-count pass of the counting sort: one digit = the cell id.
-template <typename real, class Src>
-__global__ void k_cell_assign(int n, Src src, GridP<real> g, int *__restrict__ cell_of, int *__restrict__ count) {
+// (typed boxes: the digit is cell * nt + species, so that a cell's atoms come out grouped by species)
+template <typename real, class Src, class Spc = NoSpecies>
+__global__ void k_cell_assign(int n, Src src, GridP<real> g, int *__restrict__ cell_of, int *__restrict__ count, Spc spc = Spc(),
+                              int nt = 1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;                                   // lanes past the end form their own run and add nothing
     if (i < n) {
         real x, y, z;
         src.get(i, x, y, z);
-        c = cell_id(g, x, y, z);
+        c = cell_id(g, x, y, z) * nt + spc.of(i);
         cell_of[i] = c + g.one_based;
     }
     int first, len;
@@ -292,7 +364,7 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
                               const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
                               real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
                               int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
-                              int *__restrict__ img) {
+                              int *__restrict__ img, int nt = 1) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int i = order[p];
@@ -311,7 +383,7 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
     if (im_out) im_out[p] = (owned && inv_mass) ? inv_mass[i] : (real)1;
     perm[p] = i;
     inv_perm[i] = p;
-    cell_sorted[p] = cell_of[i];
+    cell_sorted[p] = cell_of[i] / nt;
 }
 
 // Re-sort an already cell-ordered state (MD rebuild). order[p] = OLD slot of new slot p.
@@ -323,7 +395,7 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
                                 const int *__restrict__ img_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
                                 real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
                                 int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
-                                int *__restrict__ img) {
+                                int *__restrict__ img, int nt = 1) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int o = order[p];
@@ -345,7 +417,7 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
     int i = perm_in[o];
     perm[p] = i;
     inv_perm[i] = p;
-    cell_sorted[p] = cell_of[o];
+    cell_sorted[p] = cell_of[o] / nt;
 }
 
 // Operator path: same list, new caller positions -> refresh the records in place, each atom in the
@@ -371,11 +443,16 @@ __global__ void k_refresh_positions(int n, size_t pitch, GridP<real> g, const in
 template <typename real>
 __global__ void k_refresh_check(int n, size_t pitch, GridP<real> g, const int *__restrict__ perm, const real *__restrict__ pos,
                                 const emdee_lj_atom *__restrict__ atoms, const real *__restrict__ xb, Rec<real> *__restrict__ rec,
-                                float *__restrict__ te, real thr2, int *__restrict__ flags) {
+                                float *__restrict__ te, real thr2, int *__restrict__ flags, int typed = 0) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int i = perm[p];
     const emdee_lj_atom a = atoms[i], first = atoms[0];
+    if (typed) {   // a typed box is SORTED by species: an atom whose LJAtom was edited invalidates the order and the list
+        float hs0, te0;
+        rec_params(rec, te, p, hs0, te0);
+        if (__float_as_int(a.half_sigma) != __float_as_int(hs0) || __float_as_int(a.twice_sqrt_eps) != __float_as_int(te0)) flags[1] = 1;
+    }
     const real bx = xb[p], by = xb[pitch + p], bz = xb[2 * pitch + p];
     const real dx = min_image(pos[3 * (size_t)i] - bx, g.plen[0], g.pinv[0]);
     const real dy = min_image(pos[3 * (size_t)i + 1] - by, g.plen[1], g.pinv[1]);

@@ -10,6 +10,7 @@
 
 #include "brick.hpp"
 #include "kernels.hpp"
+#include "typed.hpp"
 
 namespace emdee {
 
@@ -120,6 +121,13 @@ struct NbSystem {
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
     DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, count, fill, nbr, cnt, flags, img, img2;
     DevBuf<int2> tmp2;                    // {id, sort key} in arrival order inside each cell (bin)
+    // typed boxes (two species): sort digit = cell * nt + species; count[] then holds the per-(cell, species) starts and
+    // cstart[] the per-cell ones every untyped consumer reads
+    SpeciesTable species{1, {0, 0, 0, 0}};
+    int nt = 1;
+    bool typed_enabled = std::getenv("EMDEE_NO_TYPED") == nullptr;
+    DevBuf<int> cstart;
+    DevBuf<unsigned long long> species_tab;
     DevBuf<unsigned short> nbr16;
     DevBuf<int> btab;                     // per-brick tables of the current list (k_brick_tables)
     bool btab_valid = false;
@@ -224,23 +232,31 @@ struct NbSystem {
     }
 
     // ---------------------------------------------------------------- binning
-    template <class Src>
-    void bin(Src src, const int *key) {
+    template <class Src, class Spc>
+    void bin(Src src, const int *key, Spc spc) {
         const int n = n_total;
-        count.ensure(ncell + 2); fill.ensure(ncell + 2);
-        EMDEE_HIP_CHECK(hipMemsetAsync(count.ptr, 0, (ncell + 1) * sizeof(int), stream()));
-        EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, ncell * sizeof(int), stream()));
+        const size_t nbins = ncell * (size_t)nt;
+        count.ensure(nbins + 2); fill.ensure(nbins + 2);
+        EMDEE_HIP_CHECK(hipMemsetAsync(count.ptr, 0, (nbins + 1) * sizeof(int), stream()));
+        EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, nbins * sizeof(int), stream()));
+        if (nt > 1) {
+            cstart.ensure(ncell + 2);
+            if (n == 0) EMDEE_HIP_CHECK(hipMemsetAsync(cstart.ptr, 0, (ncell + 1) * sizeof(int), stream()));
+        }
         if (n == 0) return;
-        hipLaunchKernelGGL((k_cell_assign<real, Src>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
-                           cell_of.ptr, count.ptr);
-        scanner.run(count.ptr, ncell + 1, stream());   // count[] becomes start[]
+        hipLaunchKernelGGL((k_cell_assign<real, Src, Spc>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
+                           cell_of.ptr, count.ptr, spc, nt);
+        scanner.run(count.ptr, nbins + 1, stream());   // count[] becomes the start of every (cell, species) block
         tmp2.ensure(n + 1);
         hipLaunchKernelGGL(k_cell_scatter_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            fill.ptr, key, tmp2.ptr);
         hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            tmp2.ptr, order.ptr);
+        if (nt > 1)
+            hipLaunchKernelGGL(k_cell_starts, dim3(blocks_for(ncell + 1, 256)), dim3(256), 0, stream(), (int)ncell, nt, count.ptr, cstart.ptr);
     }
-    const int *start() const { return count.ptr; }
+    const int *start() const { return nt > 1 ? cstart.ptr : count.ptr; }   // first slot of every cell
+    const int *tstart() const { return count.ptr; }                        // ... of every (cell, species) block (typed boxes)
 
     // caller-order arrays -> cell-ordered state (+ list)
     void load_user(int n_own, int n_ghost, const real *pos, const real *velocities, const emdee_lj_atom *atoms,
@@ -255,12 +271,13 @@ struct NbSystem {
         detect_uniform_atoms(atoms);
         configure_grid();
         const int n = n_total;
-        bin(UserPos<real>{pos}, nullptr);
+        if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms});
+        else bin(UserPos<real>{pos}, nullptr, NoSpecies{});
         if (n > 0)
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img.ptr);
+                               cell_sorted.ptr, img.ptr, nt);
         // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
         // from the start; their coordinates are refreshed by every halo unpack
         if (n > n_owned)
@@ -276,13 +293,14 @@ struct NbSystem {
         Timed t(this, T_REBUILD);
         const int n = n_total;
         configure_grid();
-        bin(RecPos<real>{rec.ptr}, perm.ptr);
+        if (nt > 1) bin(RecPos<real>{rec.ptr}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr});
+        else bin(RecPos<real>{rec.ptr}, perm.ptr, NoSpecies{});
         if (n > 0)
             hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
                                with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img2.ptr);
+                               cell_sorted.ptr, img2.ptr, nt);
         rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2);
         if (with_vel) vel.swap(vel2);
         if (with_mass) im.swap(im2);
@@ -310,6 +328,19 @@ struct NbSystem {
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
         a.idx_shift = idx_shift;
+        a.tstart = tstart();
+        for (int q = 0; q < 4; q++) { a.tsig2[q] = (real)0; a.te4[q] = (real)0; }
+        if (nt == 2) {
+            // sigma_ij^2 and 4 eps_ij of the four species pairs, with the operations the general-species pair loop uses
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) {
+                    float hi, ti, hj, tj;
+                    species_atom(i, hi, ti); species_atom(j, hj, tj);
+                    const real sg = (real)hi + (real)hj;
+                    a.tsig2[i * 2 + j] = sg * sg;
+                    a.te4[i * 2 + j] = (real)ti * (real)tj;
+                }
+        }
         a.refmath = (sizeof(real) == 4 && refmath && ref_pos != nullptr) ? 1 : 0;
         a.user_pos = ref_pos;
         a.thr2 = (real)(0.25 * skin * skin);
@@ -321,8 +352,34 @@ struct NbSystem {
         return a;
     }
 
+    void species_atom(int k, float &hs, float &te) const {
+        const unsigned lo = (unsigned)(species.key[k] & 0xffffffffull), hi = (unsigned)(species.key[k] >> 32);
+        memcpy(&hs, &lo, 4); memcpy(&te, &hi, 4);
+    }
+    // typed boxes (typed.hpp): variants 0 and 7 (4 lanes per atom, 512 / 1024 threads) carry the two-species kernels; masks other
+    // than FORCES run the all-outputs kernel
+    bool typed_active = false;
+    template <class V>
+    static constexpr bool typed_variant() { return std::is_same<V, BrickVariant<0>>::value || std::is_same<V, BrickVariant<7>>::value; }
+    template <class V>
+    static constexpr int typed_min_stride() { return (typed_prefetch_blocks(V::G, V::THREADS) + 1) * EPL * V::G; }
+    template <class V, int MODE, int BM>
+    void launch_typed_kernel() {
+        if constexpr (typed_variant<V>()) {
+            constexpr int M = (MODE == BRICK_STATS) ? 0 : ((MODE == BRICK_STEP || BM == 1) ? 1 : 7);
+            auto kernel = k_typed<real, typename V::Shape, V::THREADS, V::G, MODE, M>;
+            const size_t lds = typed_force_lds_bytes<real, typename V::Shape, V::THREADS>(own_cap);
+            allow_big_lds(kernel, lds);
+            const int phase = (MODE == BRICK_FORCE || MODE == BRICK_STEP) ? force_phase : 0;
+            const int blocks = (phase == 1 ? bgrid.ib_per_xcd : phase == 2 ? bgrid.bb_per_xcd : bgrid.per_xcd) * NXCD;
+            if (blocks == 0) return;
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(V::THREADS), lds, stream(), brick_args(phase));
+        }
+    }
+
     template <class V, int MODE, int BM>
     void launch_brick_kernel() {
+        if (typed_active) { launch_typed_kernel<V, MODE, BM>(); return; }
         // single-species fast path for the kernels of the MD loop (default variant only)
         if constexpr (std::is_same<V, BrickVariant<0>>::value && (MODE == BRICK_STEP || (MODE == BRICK_FORCE && (BM == 1 || BM == 7)))) {
             // (the fp64 variant keeps coordinate planes only in LDS and needs the tile to fit their fixed pitch)
@@ -467,8 +524,10 @@ struct NbSystem {
         launch_tile_max();
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 6, flags.ptr + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
-        return plan_sizes(ctx->host_flags[6], ctx->host_flags[7], ctx->host_flags[8]);
+        for (int k = 0; k < 3; k++) plan_maxima[k] = ctx->host_flags[6 + k];
+        return plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]);
     }
+    int plan_maxima[3] = {0, 0, 0};
 
     // ---------------------------------------------------------------- neighbour list
     bool brick_active = false;
@@ -493,6 +552,7 @@ struct NbSystem {
         with_brick_variant(variant, [&](auto v) {
             using V = decltype(v);
             ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
+            if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
         });
         return ok;
     }
@@ -519,12 +579,66 @@ struct NbSystem {
         // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
         if (brick_active && !build_fits_lds()) brick_active = false;
         idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !std::getenv("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
+        // two species: the typed kernels (typed.hpp), if the tile fits their coordinate planes, no three cells of a tile row hold
+        // more atoms of one species than the 16-bit hit fields of their build take, and both kernels fit LDS
+        typed_active = false;
+        if (brick_active && nt == 2 && !typed_blocked) {
+            // (where the general-species kernels take 1024 threads with 8 lanes per atom -- long cutoffs -- the typed ones take
+            // 1024 threads with 4: rows are two block-aligned segments, and blocks of 32 entries pad them half as much as blocks of 64)
+            // Measured (profiles/README.md, round 3): at rc = 3.5 sigma 190.7 -> 218.0 steps/s in fp64 and 233.8 -> 324.2 in fp32; at
+            // rc = 2.5 (variant 0, rows of ~37 entries per species) the 18 short candidate rows cost the build more than the
+            // pair loop gains, 453.9 -> 419.1: short-row boxes keep the general-species kernels (EMDEE_TYPED_ALL=1 overrides)
+            const int keep = variant, cand = (variant == 8 && !variant_forced) ? 7 : variant;
+            if (cand == 7 || (cand == 0 && std::getenv("EMDEE_TYPED_ALL") != nullptr)) {
+                variant = cand;
+                if (cand != keep) { plan_geometry(); plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]); }
+                with_brick_variant(variant, [&](auto v) {
+                    using V = decltype(v);
+                    if constexpr (typed_variant<V>()) {
+                        using S = typename V::Shape;
+                        EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 8, 0, sizeof(int), stream()));
+                        hipLaunchKernelGGL((k_typed_span_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
+                                           grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], tstart(), flags.ptr + 8);
+                        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 8, flags.ptr + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+                        const int span = ctx->host_flags[8];
+                        int st = stride;
+                        if (!typed_stride) {
+                            st = std::max(stride, typed_min_stride<V>()) + row_block;   // + the padding between the two segments
+                            st = (st + row_block - 1) / row_block * row_block;
+                        }
+                        const bool ok = tile_cap <= typed_slots<V::THREADS>() && span <= 16 * V::GB &&
+                                        typed_force_lds_bytes<real, S, V::THREADS>(own_cap) <= LDS_LIMIT &&
+                                        typed_build_lds_bytes<S, V::THREADS>(tile_cap, own_cap, st, V::GB) <= LDS_LIMIT;
+                        if (std::getenv("EMDEE_DEBUG_PLAN"))
+                            std::fprintf(stderr, "emdee plan: two species, longest 3-cell span of one species %d, stride %d, typed kernels %s\n", span, st,
+                                         ok ? "on" : "off");
+                        if (ok) {
+                            typed_active = true;
+                            stride = st;
+                            typed_stride = true;
+                            idx_shift = PLANE_SHIFT;
+                        }
+                    }
+                });
+                if (!typed_active && cand != keep) {
+                    variant = keep;
+                    plan_geometry();
+                    plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]);
+                }
+            }
+        }
+        if (!typed_active) typed_stride = false;
         plan_valid = brick_active;
         plan_uniform = uniform_atoms;
+        plan_nt = nt;
         plan_n = n;
         for (int d = 0; d < 3; d++) plan_M[d] = grid.M[d];
     }
     bool plan_uniform = false;
+    int plan_nt = 1;
+    bool typed_blocked = false;           // this state's rows outgrew the typed build (until the next load)
+    bool typed_stride = false;            // the stride already includes the typed rows' segment padding
     bool maxima_from_tables = std::getenv("EMDEE_PLAN_MAXIMA") != nullptr && std::string(std::getenv("EMDEE_PLAN_MAXIMA")) == "tables";
 
     void build_list() {
@@ -537,6 +651,7 @@ struct NbSystem {
             // builds again.  (128 instead of 96 costs 2 % of the step: 33 % more bytes flushed per build, rows 256 B apart)
             stride = (int)((expect * 1.15 + 8.0) / 16.0 + 1.0) * 16;
             if (const char *e = std::getenv("EMDEE_STRIDE")) stride = std::max(16, std::atoi(e));   // tuning: first guess of the row stride
+            typed_stride = false;
         }
         btab_valid = false;
         // The plan of the previous build of this state (variant, capacities, build kernel) is kept when the cell grid is the
@@ -544,7 +659,7 @@ struct NbSystem {
         // populations come back with the build's overflow words -- ONE blocking read-back per rebuild instead of two.
         bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && !std::getenv("EMDEE_NO_BRICK_TABLES") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
                     plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= n + n / 8 && n <= plan_n + plan_n / 8 &&
-                    plan_uniform == uniform_atoms;
+                    plan_uniform == uniform_atoms && plan_nt == nt;
         if (kept) {
             plan_geometry();
             // (taking the maxima from k_brick_tables instead, which has every brick's tables in LDS anyway, was measured and
@@ -564,6 +679,24 @@ struct NbSystem {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
+                    if constexpr (typed_variant<V>()) {
+                        if (typed_active) {   // two species: species-major tables and the two-segment build (typed.hpp)
+                            constexpr int TT = 256;
+                            using BT = TypedTables<typename V::Shape, TT>;
+                            static_assert(BT::row_ints() == TypedTables<typename V::Shape, V::THREADS>::row_ints(), "table row layout");
+                            btab.ensure((size_t)bgrid.nbricks * BT::row_ints());
+                            BrickArgs<real> ta = brick_args();
+                            ta.btab = btab.ptr;
+                            hipLaunchKernelGGL((k_typed_tables<real, typename V::Shape, TT>), dim3(bgrid.per_xcd * NXCD), dim3(TT),
+                                               BT::bytes(0), stream(), ta);
+                            btab_valid = true;
+                            auto kernel = k_typed_build<real, typename V::Shape, V::THREADS, V::GB, V::G>;
+                            lds_build_bytes = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
+                            allow_big_lds(kernel, lds_build_bytes);
+                            hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(), brick_args());
+                            return;
+                        }
+                    }
                     if (!btab_valid && !std::getenv("EMDEE_NO_BRICK_TABLES")) {
                         // tables of every brick, once per rebuild; the build and every force launch copy them in
                         // (the image depends on the brick shape only: a small workgroup writes it)
@@ -629,6 +762,15 @@ struct NbSystem {
             }
             stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
             if (brick_active) stride = (stride + row_block - 1) / row_block * row_block;
+            if (brick_active && typed_active && !build_fits_lds()) {
+                // rows longer than the typed build's LDS row buffers can take: this state goes on with the general-species kernels
+                typed_blocked = true;
+                plan_valid = false;
+                btab_valid = false;
+                kept = false;
+                make_plan();
+                continue;
+            }
             if (brick_active && !build_fits_lds()) { brick_active = false; idx_shift = 0; btab_valid = false; plan_valid = false; }
         }
         EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
@@ -660,15 +802,39 @@ struct NbSystem {
     int uniform_known = -1;
     emdee_lj_atom uni_first{0.f, 0.f};
     void detect_uniform_atoms(const emdee_lj_atom *atoms) {
+        nt = 1;
+        species.n = 1;
+        typed_blocked = false;
         if (uniform_known >= 0 && n_total > 0) { uniform_atoms = uniform_known == 1; return; }
         uniform_atoms = false;
         if (n_total == 0 || std::getenv("EMDEE_NO_UNIFORM")) return;
         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));
         hipLaunchKernelGGL(k_atoms_differ, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, atoms, flags.ptr + 5);
+        // the distinct LJAtom values, if there are few (two: the box is sorted by species and takes the typed kernels)
+        unsigned long long tab[MAX_SPECIES + 1];
+        // (Float32 operator calls run the reference's arithmetic on the general-species kernels: those read untyped rows)
+        const bool want_species = typed_enabled && !(sizeof(real) == 4 && refmath);
+        if (want_species) {
+            species_tab.ensure(MAX_SPECIES + 1);
+            EMDEE_HIP_CHECK(hipMemsetAsync(species_tab.ptr, 0xff, MAX_SPECIES * sizeof(unsigned long long), stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(species_tab.ptr + MAX_SPECIES, 0, sizeof(unsigned long long), stream()));
+            hipLaunchKernelGGL(k_species_collect, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, atoms, species_tab.ptr);
+            EMDEE_HIP_CHECK(hipMemcpyAsync(tab, species_tab.ptr, sizeof(tab), hipMemcpyDeviceToHost, stream()));
+        }
         emdee_lj_atom first;
         EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 5, flags.ptr + 5, sizeof(int), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        if (want_species && tab[MAX_SPECIES] == 0) {
+            int found = 0;
+            for (int q = 0; q < MAX_SPECIES; q++) found += tab[q] != ~0ull ? 1 : 0;
+            if (found == 2) {                                    // (the typed kernels are built for two species)
+                std::sort(tab, tab + 2);                         // numbering by value, not by who arrived first
+                species.n = 2;
+                species.key[0] = tab[0]; species.key[1] = tab[1];
+                nt = 2;
+            }
+        }
         uni_first = first;
         if (ctx->host_flags[5] == 0 && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
@@ -890,6 +1056,15 @@ struct NbSystem {
         if (brick_active) {
             with_brick_variant(variant, [&](auto v) {
                 using V = decltype(v);
+                if constexpr (typed_variant<V>()) {
+                    if (typed_active) {
+                        auto tk = k_typed_export<real, typename V::Shape, V::THREADS, V::G>;
+                        using TTab = TypedTables<typename V::Shape, V::THREADS>;
+                        const size_t tlds = TTab::bytes(0);
+                        hipLaunchKernelGGL(tk, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), tlds, stream(), brick_args(), counts, out, capacity);
+                        return;
+                    }
+                }
                 auto kernel = k_brick_export<real, typename V::Shape, V::THREADS, V::G>;
                 using BT = BrickTables<typename V::Shape, V::THREADS>;
                 const size_t lds = BT::bytes(0);
@@ -930,7 +1105,7 @@ struct NbSystem {
         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 1, 0, sizeof(int), stream()));
         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));
         hipLaunchKernelGGL((k_refresh_check<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, pitch,
-                           grid, perm.ptr, pos, atoms, xb.ptr, rec.ptr, te.ptr, thr * thr, flags.ptr);
+                           grid, perm.ptr, pos, atoms, xb.ptr, rec.ptr, te.ptr, thr * thr, flags.ptr, nt > 1 ? 1 : 0);
         emdee_lj_atom first;
         EMDEE_HIP_CHECK(hipMemcpyAsync(&first, atoms, sizeof(first), hipMemcpyDeviceToHost, stream()));
         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 6 * sizeof(int), hipMemcpyDeviceToHost, stream()));

@@ -222,3 +222,71 @@ def test_same_box_with_very_different_density_profiles(emdee, oracle, dev):
         scale = np.abs(fo).max()
         assert np.abs(f.cpu().numpy() - fo).max() <= 1e-9 * scale
     assert tiles.stats()["builds"] >= 3
+
+
+@pytest.mark.parametrize("rc,rs,cells", [(2.5, 2.0, 23), (3.5, 3.0, 29)])    # (cell side just above rc + skin, as in the 10^7-atom boxes: the tiles fit the typed planes)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_species_boxes_take_the_typed_kernels(emdee, oracle, dev, capfd, monkeypatch, rc, rs, cells, dtype):
+    """Two distinct LJAtom values: the box is sorted by (cell, species), tiles are staged species-major, rows are built as one
+    segment per neighbour species and the pair loop runs per segment with the pair constants in registers (csrc/typed.hpp;
+    rc = 2.5: 512-thread workgroups, rc = 3.5: 1024).  Same per-pair arithmetic as the general-species kernels
+    (EMDEE_NO_TYPED=1), which serve as the second witness next to the oracle: operator outputs, the neighbour SET, counted
+    pairs and a trajectory."""
+    E = emdee
+    syn = E.synthetic
+    pos, L = syn.fcc_positions(cells)
+    N = pos.shape[0]
+    pos = pos + 0.25 * (np.random.default_rng(7).random(pos.shape) - 0.5)
+    types = syn.mixture_types(N)
+    eps, sigma = syn.mixture_parameters(types)
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    model = E.LennardJonesModel(rc, rs)
+    x = pos.astype(dtype)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    out = {}
+    for typed in (True, False):
+        if typed:
+            monkeypatch.delenv("EMDEE_NO_TYPED", raising=False)
+            monkeypatch.setenv("EMDEE_F32_FAST", "1")          # (Float32 operator calls otherwise run the reference arithmetic on the general-species kernels)
+        else:
+            monkeypatch.setenv("EMDEE_NO_TYPED", "1")
+        monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+        monkeypatch.setenv("EMDEE_TYPED_ALL", "1")             # short rows too (by default only the long-row boxes, where they win)
+        capfd.readouterr()
+        tiles = E.nonbonded_computation_tiles(N)
+        f = torch.zeros((N, 3), dtype=tdt, device=dev)
+        e = torch.zeros(N, dtype=tdt, device=dev)
+        w = torch.zeros(N, dtype=tdt, device=dev)
+        E.compute_nonbonded_(f, e, w, E.cu(x, dev), L, tiles, model, E.cu(atoms, dev), 7)
+        torch.cuda.synchronize()
+        err = capfd.readouterr().err
+        assert ("typed kernels on" in err) == typed, err[-400:]
+        f1 = torch.zeros((N, 3), dtype=tdt, device=dev)
+        E.compute_nonbonded_(f1, None, None, E.cu(x, dev), L, tiles, model, E.cu(atoms, dev), 1)     # the forces-only kernel
+        out[typed] = dict(f=f.cpu().numpy(), e=e.cpu().numpy(), w=w.cpu().numpy(), f1=f1.cpu().numpy(), rows=_rows(*tiles.neighbor_lists()),
+                          pairs=tiles.count_pairs(), stats=tiles.stats())
+        vel = syn.velocities(N)
+        md = E.VelocityVerlet(E.cu(x, dev), E.cu(vel.astype(dtype), dev), L, model, E.cu(atoms, dev))
+        md.step_(12, 0.004)
+        out[typed]["x12"] = md.state()["positions"].cpu().numpy()
+        out[typed]["md_pairs"] = md.count_pairs()
+        md.close()
+    monkeypatch.delenv("EMDEE_DEBUG_PLAN", raising=False)
+    a, b = out[True], out[False]
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    for k in ("f", "e", "w", "f1"):
+        assert np.abs(a[k] - b[k]).max() <= tol * np.abs(b[k]).max(), k
+    assert np.abs(a["f1"] - a["f"]).max() <= tol * np.abs(a["f"]).max()
+    assert a["pairs"] == b["pairs"] and a["md_pairs"] == b["md_pairs"]
+    assert a["stats"]["listed"] == b["stats"]["listed"] and a["stats"]["max_count"] == b["stats"]["max_count"]
+    for i in range(N):
+        assert np.array_equal(a["rows"][i], b["rows"][i]), "row %d: typed and general-species builds disagree" % i
+    dx = a["x12"] - b["x12"]
+    assert np.abs(dx - L * np.rint(dx / L)).max() < (1e-10 if dtype == np.float64 else 2e-4)
+    if dtype == np.float64:
+        f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(rc, rs), atoms)
+        assert np.abs(a["f"] - f0).max() <= 1e-9 * np.abs(f0).max()
+        assert np.abs(a["e"] - e0).max() <= 1e-9 * np.abs(e0).max() and np.abs(a["w"] - w0).max() <= 1e-9 * np.abs(w0).max()
+        want = _oracle_rows(oracle, pos, L, rc + 0.3)
+        for i in range(N):
+            assert np.array_equal(a["rows"][i], want[i]), "row %d differs from the oracle's" % i
