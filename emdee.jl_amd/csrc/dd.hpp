@@ -488,8 +488,38 @@ struct DdImpl : IDd {
         const bool uni = agreed == (double)world;
         for (auto &d : dom) {
             d->sys().uniform_known = uni ? 1 : 0;
+            d->sys().species_known.n = 1;
             if (uni) d->sys().set_uniform_constants(emdee_lj_atom{unbits(sum[2] / voters), unbits(sum[3] / voters)});
         }
+        if (uni || voters == 0) return;
+        // Two species everywhere?  Then every engine sorts by (cell, species) and takes the typed kernels where they pay
+        // (typed.hpp).  Every domain with atoms must have found the same two LJAtom bit patterns (an empty one has no opinion).
+        auto half = [](unsigned long long k, int h) { return (double)(unsigned)(h ? (k >> 32) : (k & 0xffffffffull)); };
+        std::vector<std::vector<double>> t;
+        for (auto &d : dom) {
+            const NbSystem<real> &e = d->sys();
+            const bool two = e.n_total > 0 && e.species.n == 2;
+            t.push_back({e.n_total > 0 ? 1.0 : 0.0, two ? 1.0 : 0.0, two ? half(e.species.key[0], 0) : 0.0, two ? half(e.species.key[0], 1) : 0.0,
+                         two ? half(e.species.key[1], 0) : 0.0, two ? half(e.species.key[1], 1) : 0.0});
+        }
+        double ts[6];
+        allreduce_sum(t, 6, ts);
+        std::vector<std::vector<double>> ok2;
+        for (auto &d : dom) {
+            const NbSystem<real> &e = d->sys();
+            bool same = ts[0] > 0 && ts[1] == ts[0];
+            if (same && e.n_total > 0)
+                same = ts[2] == ts[0] * half(e.species.key[0], 0) && ts[3] == ts[0] * half(e.species.key[0], 1) &&
+                       ts[4] == ts[0] * half(e.species.key[1], 0) && ts[5] == ts[0] * half(e.species.key[1], 1);
+            ok2.push_back({same ? 1.0 : 0.0});
+        }
+        double agreed2 = 0;
+        allreduce_sum(ok2, 1, &agreed2);
+        if (agreed2 != (double)world) return;
+        SpeciesTable tab{2, {0, 0, 0, 0}};
+        for (int k = 0; k < 2; k++)
+            tab.key[k] = (unsigned long long)(unsigned)(ts[2 + 2 * k] / ts[0] + 0.5) | ((unsigned long long)(unsigned)(ts[3 + 2 * k] / ts[0] + 0.5) << 32);
+        for (auto &d : dom) d->sys().species_known = tab;
     }
 
     // stable partition of items 0..n-1 by mask bits into nbins bins.  partition_prepare sizes and clears the per-block

@@ -800,12 +800,18 @@ struct NbSystem {
     // uniform_known: -1 = look at the atoms at every load; 0 / 1 = the caller vouches that the species set is mixed /
     // single (emdee_dd_*: agreed once over all domains; atoms only change owner afterwards) and the scan + read-back are skipped
     int uniform_known = -1;
+    SpeciesTable species_known{1, {0, 0, 0, 0}};   // with uniform_known == 0: the box's two species, if it has exactly two
     emdee_lj_atom uni_first{0.f, 0.f};
     void detect_uniform_atoms(const emdee_lj_atom *atoms) {
         nt = 1;
         species.n = 1;
         typed_blocked = false;
-        if (uniform_known >= 0 && n_total > 0) { uniform_atoms = uniform_known == 1; return; }
+        if (uniform_known >= 0 && n_total > 0) {
+            uniform_atoms = uniform_known == 1;
+            // (decomposed runs: the two species every domain agreed on at the first load, emdee_dd_load)
+            if (!uniform_atoms && species_known.n == 2 && typed_enabled) { species = species_known; nt = 2; }
+            return;
+        }
         uniform_atoms = false;
         if (n_total == 0 || std::getenv("EMDEE_NO_UNIFORM")) return;
         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 5, 0, sizeof(int), stream()));

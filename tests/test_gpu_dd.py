@@ -284,6 +284,47 @@ def test_dd_with_an_empty_domain(emdee, oracle):
     dd.close()
 
 
+def test_dd_two_species_long_cutoff_takes_the_typed_kernels(emdee, capfd, monkeypatch):
+    """BASELINE configs[4] decomposed, at a size where every domain's tiles are those of the 10^7-atom box (rc = 3.5 sigma,
+    97,556 atoms, 2 domains): the domains agree on the box's two species at the load, every engine then sorts by
+    (cell, species) and steps with the typed kernels (csrc/typed.hpp), interior and boundary phases, guard words and all.
+    Checked against the undivided integrator on the same GPU and, through it, against the general-species kernels."""
+    E = emdee
+    dev = torch.device("cuda", 0)
+    rc, rs = 3.5, 3.0
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, ncell=29)
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    model = E.LennardJonesModel(rc, rs)
+    monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+    capfd.readouterr()
+    dd = E.DomainDecomposition([L] * 3, (2, 1, 1), model, skin=SKIN, device=dev)
+    for r in range(2):
+        mine = np.arange(r, N, 2)
+        dd.set_atoms_(r, E.cu(pos[mine], dev), E.cu(vel[mine], dev), E.cu(atoms[mine], dev), torch.from_numpy(mine).to(dev))
+    dd.load_()
+    dd.step_(20, DT, 0)
+    e_dd = dd.totals()
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    assert err.count("typed kernels on") >= 2, err[-600:]                 # both domains, at the load and after it
+    monkeypatch.setenv("EMDEE_NO_TYPED", "1")                             # the witness: the general-species kernels, undivided
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, model, E.cu(atoms, dev), skin=SKIN)
+    md.step_(20, DT, 0)
+    torch.cuda.synchronize()
+    assert "typed kernels on" not in capfd.readouterr().err
+    st = md.state()
+    x, v, f = _gather(dd, 2, N)
+    dx = x - st["positions"].cpu().numpy()
+    assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
+    assert np.abs(v - st["velocities"].cpu().numpy()).max() < 1e-8
+    assert np.abs(f - st["forces"].cpu().numpy()).max() < 1e-6 * np.abs(f).max()
+    e_md = md.totals()
+    assert e_dd[0] == pytest.approx(e_md[0], rel=1e-10) and e_dd[1] == pytest.approx(e_md[1], rel=1e-10)
+    assert dd.stats()["rebuilds"] >= 3
+    dd.close()
+
+
 def test_rccl_binding_on_one_rank(emdee):
     """The RCCL transport cannot run between two ranks on a one-GPU box; what can be checked here is the run-time
     binding it rests on: librccl resolved with dlopen, ncclGetUniqueId / ncclCommInitRank (the 128-byte id by value),
