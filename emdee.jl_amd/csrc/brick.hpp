@@ -781,6 +781,16 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         // or 16-byte records with 4 lanes per atom, an 8-way LDS bank conflict for 32-byte records read by 8 lanes (measured
         // on the rc = 3.5 mixture: build 8.1 -> 6.6 ms, force 4.1 -> 6.0 ms) -- the host picks ALG 13/15 only for the former.
         constexpr bool STRIDED = RT && EMDEE_BUILD_STRIDED != 0 && ALG >= 10;
+#ifndef EMDEE_BUILD_PAIR_OPPOSITE
+#define EMDEE_BUILD_PAIR_OPPOSITE 1
+#endif
+        // Which two tile rows share a 32-bit word of hit bits (16-bit fields).  The emission loop of a word runs as long as
+        // the busiest of the 64 lanes has hits in it, and an atom near a face of its cell has many hits in the row beyond
+        // that face and few in the opposite one: rows (dy, dz) and (-dy, -dz) in one word -- (0,8) (1,7) (2,6) (3,5) (4) --
+        // have a nearly constant sum where neighbouring rows (0,1) (2,3) ... do not.
+        constexpr bool OPP = EMDEE_BUILD_PAIR_OPPOSITE != 0 && PER == 2;
+        auto row_word = [](int r) constexpr { return OPP ? (r <= 4 ? r : 8 - r) : r / PER; };
+        auto row_half = [](int r) constexpr { return OPP ? (r > 4 ? 1 : 0) : r % PER; };
         constexpr int LOG2G = G == 8 ? 3 : 4, KSTEP = STRIDED ? G : 1;
         for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
             const int o = ob + gid;
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 // my candidates (may be <= 0 in the chunked form): slots cb + k KSTEP, k < lim
                 const int lim = STRIDED ? (int)((unsigned)(span - gl + G - 1) >> LOG2G) : min(chunk, span - first);
                 const int cb = c0 + first;
-                cbase[r] = cb - (r % PER) * FIELD * KSTEP;
+                cbase[r] = cb - row_half(r) * FIELD * KSTEP;
                 // scalar (chunk is the same in all lanes of a group); unrolled UNR times
 #ifdef EMDEE_BUILD_ABLATE      // timing experiments only (the lists are wrong): 1 no candidate loop, 2 no emission, 4 no flush
                 const int trips = (EMDEE_BUILD_ABLATE & 1) ? 0 : (RT ? trips_of[r] : ((wave_group_max<G>(chunk) + UNR - 1) & ~(UNR - 1)));
@@ -941,8 +951,8 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                         if (ks >= 0 && ks < lim) bits &= ~(1u << ks);
                     }
                 }
-                if (r % PER) word[r / PER] |= bits << ((r % PER) * FIELD);
-                else word[r / PER] = bits;
+                if (row_half(r)) word[row_word(r)] |= bits << (row_half(r) * FIELD);
+                else word[row_word(r)] = bits;
             }
             // ---- phase 2 (as ALG 2): prefix over the lanes of the group, then every lane emits its hits --------
             int mine = 0;
@@ -974,7 +984,8 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
 #ifdef EMDEE_BUILD_ABLATE
                 if (EMDEE_BUILD_ABLATE & 2) W = 0;
 #endif
-                int cA = cbase[PER * w] << a.idx_shift, cB = ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0) << a.idx_shift;
+                int cA = cbase[OPP ? w : PER * w] << a.idx_shift,
+                    cB = (OPP ? (w < 4 ? cbase[8 - w] : 0) : ((PER == 2 && 2 * w + 1 < NROWS) ? cbase[2 * w + 1] : 0)) << a.idx_shift;
                 asm volatile("" : "+v"(cA), "+v"(cB));                             // shifted once, here
                 const int kshift = a.idx_shift + (STRIDED ? LOG2G : 0);          // bit k of a field is slot cb + k KSTEP
                 while (W) {

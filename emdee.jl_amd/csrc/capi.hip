@@ -68,13 +68,12 @@ int32_t emdee_ctx_create(int32_t device_id, void *stream, emdee_ctx **out) {
         ctx->cu_count = prop.multiProcessorCount;
         ctx->hbm_bytes = prop.totalGlobalMem;
         snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
-        hipError_t he = hipHostMalloc((void **)&ctx->host_flags, 16 * sizeof(int32_t), hipHostMallocDefault);
-        if (he != hipSuccess) {
+        try {
+            host_words_alloc(ctx);
+        } catch (...) {
             delete ctx;
-            set_error("hipHostMalloc failed: %s", hipGetErrorString(he));
-            throw Failure{EMDEE_ERR_ALLOC};
+            throw;
         }
-        memset(ctx->host_flags, 0, 16 * sizeof(int32_t));
         *out = ctx;
     });
 }
@@ -500,6 +499,9 @@ int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, ui
 }
 int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]) {
     return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->stats(out); });
+}
+int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->rebuild_stats(out); });
 }
 int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap) {
     return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->set_overlap(overlap != 0); });

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,7 +69,11 @@ struct emdee_ctx {
     int cu_count = 0;
     size_t hbm_bytes = 0;
     char arch[64] = {0};
-    int32_t *host_flags = nullptr;   // pinned, 16 ints, for small blocking read-backs
+    int32_t *host_flags = nullptr;   // pinned, device-visible: [0, 16) small blocking read-backs (copy + synchronize),
+                                     // [POST_DATA, POST_DATA + POST_MAX) + stamp at POST_STAMP: read-backs posted by a kernel
+    int32_t *post_dev = nullptr;     // the same memory as the device sees it
+    uint32_t post_seq = 0;
+    bool post_copy = false;          // EMDEE_READBACK=copy: every read-back as copy + synchronize (A/B)
 };
 
 namespace emdee {
@@ -110,6 +115,59 @@ struct DevBuf {
 };
 
 static inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// ------------------------------------------------------------------------------------ small blocking read-backs
+// A rebuild decision, the build's overflow words, the counts of a migration: a few words the host must see before it can
+// queue the next kernel.  hipMemcpyAsync + hipStreamSynchronize leaves 16 us of empty queue behind the producing kernel
+// on this machine; a one-workgroup kernel that writes the words and then a sequence stamp straight into pinned host
+// memory (system-scope release), with the host spinning on the stamp, leaves 6 (profiles/tools/readback_latency.hip).
+constexpr int HOST_WORDS = 256, POST_DATA = 64, POST_MAX = 128, POST_STAMP = 200;
+
+static inline void host_words_alloc(emdee_ctx *ctx) {
+    EMDEE_HIP_CHECK(hipHostMalloc((void **)&ctx->host_flags, HOST_WORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->host_flags, 0, HOST_WORDS * sizeof(int32_t));
+    EMDEE_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->post_dev, ctx->host_flags, 0));
+    ctx->post_seq = 0;
+    const char *e = std::getenv("EMDEE_READBACK");
+    ctx->post_copy = e != nullptr && std::string(e) == "copy";
+}
+
+static __global__ void k_post_words(const int *__restrict__ src, int n, volatile int *dst, volatile int *stamp, int seq) {
+    const int t = threadIdx.x;
+    if (t < n) dst[t] = src[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) *stamp = seq;
+}
+
+// n <= POST_MAX words of device memory, as they are when the work queued on s so far has run -> out (host); blocking
+static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev, int n, int32_t *out) {
+    EMDEE_REQUIRE(n >= 0 && n <= POST_MAX, EMDEE_ERR_INVALID, "read_back_words: %d words", n);
+    if (n == 0) return;
+    int32_t *data = ctx->host_flags + POST_DATA;
+    if (ctx->post_copy || ctx->post_dev == nullptr) {
+        EMDEE_HIP_CHECK(hipMemcpyAsync(data, dev, n * sizeof(int), hipMemcpyDeviceToHost, s));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        if (++ctx->post_seq == 0) ++ctx->post_seq;                         // never 0 (the buffer's initial contents)
+        const int seq = (int)ctx->post_seq;
+        hipLaunchKernelGGL(k_post_words, dim3(1), dim3(POST_MAX), 0, s, dev, n, (volatile int *)(ctx->post_dev + POST_DATA),
+                           (volatile int *)(ctx->post_dev + POST_STAMP), seq);
+        volatile int32_t *stamp = ctx->host_flags + POST_STAMP;
+        for (unsigned spins = 1; *stamp != seq; spins++) {
+            if ((spins & 0x3fffu) == 0) {                                  // a stream that failed would never stamp
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {
+                    EMDEE_REQUIRE(*stamp == seq, EMDEE_ERR_HIP, "read-back: the stream drained without posting its words");
+                } else if (q != hipErrorNotReady) {
+                    EMDEE_HIP_CHECK(q);
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    for (int k = 0; k < n; k++) out[k] = ((volatile int32_t *)data)[k];
+}
 
 // HIP-event pair pool for per-kernel device timing on the context's stream (bench.py's
 // roofline numbers come from here).

@@ -214,6 +214,11 @@ struct Domain {
     Scanner scanner;
     int n_owned = 0, n_ghost = 0, n_send = 0;
     int host_small[96];
+    // count-free rebuilds (dd_kernels.hpp): capacities both ends of a message know, the words of the one read-back
+    DdCaps mig_caps{}, gs_caps{}, gr_caps{};
+    bool have_caps = false;
+    DevBuf<int> w;
+    int host_w[DDW_COUNT];
     DdPlan plan{};
     Xfer xf{};
     int since_build = 0;
@@ -240,6 +245,9 @@ struct DdImpl : IDd {
     int max_batch = DD_MAX_BATCH;
     bool overlap = true;
     bool two_streams = true;              // EMDEE_DD_STREAMS=1: interior and boundary launches on one stream
+    bool no_shortcut = false;             // EMDEE_DD_NO_SHORTCUT=1: a one-domain grid goes through the whole ownership path (profiling)
+    bool count_free = true;               // EMDEE_DD_COUNT_FREE=0: every rebuild exchanges its row counts first (round 2)
+    int64_t stat_fast = 0, stat_fallback = 0;
     int last_interval = 0;
     // Langevin
     bool lgv_on = false;
@@ -282,6 +290,8 @@ struct DdImpl : IDd {
         if (const char *e = std::getenv("EMDEE_DD_BATCH")) max_batch = std::max(1, std::min(DD_MAX_BATCH, std::atoi(e)));
         if (const char *e = std::getenv("EMDEE_DD_OVERLAP")) overlap = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_STREAMS")) two_streams = std::atoi(e) != 1;
+        if (const char *e = std::getenv("EMDEE_DD_NO_SHORTCUT")) no_shortcut = std::atoi(e) != 0;
+        if (const char *e = std::getenv("EMDEE_DD_COUNT_FREE")) count_free = std::atoi(e) != 0;
         for (int l = 0; l < n_local; l++) {
             dom.push_back(std::make_unique<Domain<real>>());   // registered first: release() sees whatever it gets below
             Domain<real> *d = dom.back().get();
@@ -294,8 +304,8 @@ struct DdImpl : IDd {
                 d->ctx->stream = nullptr;
                 d->ctx->host_flags = nullptr;
                 EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->ctx->stream, hipStreamNonBlocking));
-                EMDEE_HIP_CHECK(hipHostMalloc((void **)&d->ctx->host_flags, 16 * sizeof(int32_t), hipHostMallocDefault));
-                memset(d->ctx->host_flags, 0, 16 * sizeof(int32_t));
+                d->ctx->post_dev = nullptr;
+                host_words_alloc(d->ctx);
             }
             EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
             EMDEE_HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
@@ -557,6 +567,10 @@ struct DdImpl : IDd {
         }
         exchange();
         wait_exchange();
+        if (dom.size() == 1) {
+            read_back_words(dom[0]->ctx, dom[0]->stream(), dom[0]->small.ptr, 96, dom[0]->host_small);
+            return;
+        }
         for (auto &pd : dom)
             EMDEE_HIP_CHECK(hipMemcpyAsync(pd->host_small, pd->small.ptr, 96 * sizeof(int), hipMemcpyDeviceToHost, pd->stream()));
         for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
@@ -578,27 +592,34 @@ struct DdImpl : IDd {
         wait_exchange();
     }
 
-    void redistribute(bool from_engines) {
+    // with_forces = false: the caller follows up with step_after_rebuild, whose fused kernel evaluates them
+    void redistribute(bool from_engines, bool with_forces = true) {
         struct Scope {
             bool &f;
             explicit Scope(bool &b) : f(b) { f = true; }
             ~Scope() { f = false; }
         } scope(in_rebuild);
-        if (world == 1 && from_engines) {
+        if (world == 1 && from_engines && !no_shortcut) {
             // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
             // none of the ownership passes and their two count read-backs)
             Domain<real> &d = *dom[0];
             d.md->rebuild();
-            d.md->forces(EMDEE_FORCES, 0);
+            if (with_forces) d.md->forces(EMDEE_FORCES, 0);
             d.since_build = 0;
             EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
             stat_rebuilds++;
             return;
         }
         // ---- 0. caller-order copies of the integrated state
+        bool unsorted = false;
+        if (from_engines && count_free && dom[0]->have_caps) {
+            if (redistribute_count_free(with_forces)) return;
+            unsorted = true;                                        // a capacity was exceeded somewhere: everybody redoes it with counts
+            stat_fallback++;
+        }
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            if (from_engines) {
+            if (from_engines && !unsorted) {
                 d.x.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3);   // (never grows here: sized at the previous load)
                 d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr);
             }
@@ -693,17 +714,157 @@ struct DdImpl : IDd {
                 hipLaunchKernelGGL((k_dd_unpack_ghost_rows<real>), dim3(blocks_for(d.n_ghost, 256)), dim3(256), 0, d.stream(), d.n_ghost,
                                    reinterpret_cast<const GhostRow<real> *>(d.recvbuf.ptr), d.x.ptr + 3 * (size_t)d.n_owned,
                                    d.at.ptr + d.n_owned);
-            d.md->set_state(d.n_owned, d.n_ghost, d.x.ptr, d.v.ptr, d.at.ptr, nullptr);
-            if (lgv_on) d.md->set_langevin_ids(reinterpret_cast<const int64_t *>(d.gid.ptr));
-            d.since_build = 0;
-            // per-step messages: header + 3 reals per atom and peer
-            const size_t w = sizeof(real);
-            const int np = d.geo.npeers;
-            d.sendbuf.ensure(dd_msg_begin(d.plan.send_start, np, w) + 64);
-            d.recvbuf.ensure(dd_msg_begin(d.plan.recv_start, np, w) + 64);
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            load_engine(d, with_forces);
         }
         stat_rebuilds++;
+    }
+
+    // capacity of a ghost message at the next rebuild, from its rows at this one (both ends hold the same number)
+    static int ghost_cap(int rows) { return rows + rows / 8 + 64; }
+    void set_caps(Domain<real> &d) {
+        const int np = d.geo.npeers;
+        const int64_t per_rank = n_global > 0 ? n_global / world : (int64_t)d.n_owned;
+        int mig = (int)std::max<int64_t>(256, per_rank / 512);
+        if (const char *e = std::getenv("EMDEE_DD_MIG_CAP")) mig = std::max(1, std::atoi(e));   // tests: force the fallback
+        d.mig_caps.npeers = d.gs_caps.npeers = d.gr_caps.npeers = np;
+        d.mig_caps.start[0] = d.gs_caps.start[0] = d.gr_caps.start[0] = 0;
+        for (int p = 0; p < np; p++) {
+            d.mig_caps.start[p + 1] = d.mig_caps.start[p] + mig;
+            d.gs_caps.start[p + 1] = d.gs_caps.start[p] + ghost_cap(d.plan.send_start[p + 1] - d.plan.send_start[p]);
+            d.gr_caps.start[p + 1] = d.gr_caps.start[p] + ghost_cap(d.plan.recv_start[p + 1] - d.plan.recv_start[p]);
+        }
+        d.have_caps = n_global > 0;       // (the first load runs before the global count is known)
+    }
+    // step 4 of a rebuild: bin, sort, neighbour list (forces); buffers of the per-step messages; capacities of the next rebuild
+    void load_engine(Domain<real> &d, bool with_forces) {
+        d.md->defer_forces = !with_forces;
+        d.md->set_state(d.n_owned, d.n_ghost, d.x.ptr, d.v.ptr, d.at.ptr, nullptr);
+        d.md->defer_forces = false;
+        if (lgv_on) d.md->set_langevin_ids(reinterpret_cast<const int64_t *>(d.gid.ptr));
+        d.since_build = 0;
+        set_caps(d);
+        // per-step messages: header + 3 reals per atom and peer; the padded messages of the next rebuild share the buffers
+        const size_t w = sizeof(real);
+        const int np = d.geo.npeers;
+        const size_t pad_s = std::max(dd_pad_total(d.mig_caps, sizeof(MigRow<real>)), dd_pad_total(d.gs_caps, sizeof(GhostRow<real>)));
+        const size_t pad_r = std::max(dd_pad_total(d.mig_caps, sizeof(MigRow<real>)), dd_pad_total(d.gr_caps, sizeof(GhostRow<real>)));
+        d.sendbuf.ensure(std::max(dd_msg_begin(d.plan.send_start, np, w), pad_s) + 64);
+        d.recvbuf.ensure(std::max(dd_msg_begin(d.plan.recv_start, np, w), pad_r) + 64);
+        EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+    }
+
+    // A rebuild without count exchanges (dd_kernels.hpp, "count-free rebuild messages"): two padded exchanges, device-side
+    // counts in between, ONE read-back.  False: a capacity was exceeded on some rank -- every rank sees that in the headers it
+    // received, nothing has been committed (the new owned arrays were written to the spare buffers), and the caller redoes the
+    // rebuild with exact counts from the caller-order copies made here.
+    bool redistribute_count_free(bool with_forces) {
+        const size_t mrow = sizeof(MigRow<real>), grow = sizeof(GhostRow<real>);
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int np = d.geo.npeers, n_up = d.n_owned + d.mig_caps.start[np];
+            d.x.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3);
+            d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr);
+            d.mask.ensure((size_t)n_up + 1);
+            d.w.ensure(DDW_COUNT);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
+            // ---- 1. owner of every atom; stable partition into stay | one bin per peer (every atom sits in exactly one bin)
+            const int nb1 = 1 + np, nblk1 = partition_prepare(d, d.n_owned, nb1);
+            if (d.n_owned > 0)
+                hipLaunchKernelGGL((k_dd_classify<real>), dim3(nblk1), dim3(PART_BLOCK), 0, d.stream(), d.n_owned, d.x.ptr,
+                                   d.geo.template device<real>(), d.mask.ptr, d.small.ptr + 95, nb1, nblk1, d.counts.ptr);
+            DdBins pb{};
+            pb.npeers = np;
+            for (int p = 0; p <= np + 1; p++) pb.lo[p] = std::min(1 + p, 1 + np);
+            partition_finish(d, nb1, nblk1, pb);
+            d.ids.ensure((size_t)std::max(n_up, d.gs_caps.start[np]) + 1);
+            d.bins.ensure((size_t)d.gs_caps.start[np] + 1);
+            d.codes.ensure((size_t)d.gs_caps.start[np] + 1);
+            partition_scatter(d, d.n_owned, nb1, d.n_owned, false);
+            // ---- 2. the leavers travel in padded messages
+            const int nt = std::max(1, std::max(np, d.mig_caps.start[np]));
+            hipLaunchKernelGGL((k_dd_pack_migrants_padded<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
+                               d.small.ptr, d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, d.sendbuf.ptr);
+            for (int p = 0; p < np; p++) {
+                d.xf.soff[p] = d.xf.roff[p] = dd_pad_msg_begin(d.mig_caps, p, mrow);
+                d.xf.sbytes[p] = d.xf.rbytes[p] = dd_pad_msg_bytes(d.mig_caps, p, mrow);
+            }
+            d.xf.send = d.sendbuf.ptr;
+            d.xf.recv = d.recvbuf.ptr;
+            record_packed(d);
+        }
+        exchange();
+        wait_exchange();
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int np = d.geo.npeers, n_up = d.n_owned + d.mig_caps.start[np];
+            hipLaunchKernelGGL((k_dd_migrant_counts<real>), dim3(1), dim3(64), 0, d.stream(), d.mig_caps, d.small.ptr, d.small.ptr + 95,
+                               d.recvbuf.ptr, d.w.ptr);
+            const size_t room = (size_t)n_up + (size_t)d.gr_caps.start[np];      // owned + ghosts of the new state
+            d.x2.ensure(3 * room + 3); d.v2.ensure(3 * (size_t)n_up + 3); d.at2.ensure(room + 1); d.gid2.ensure((size_t)n_up + 1);
+            hipLaunchKernelGGL((k_dd_assemble_padded<real>), dim3(blocks_for(std::max(1, n_up), 256)), dim3(256), 0, d.stream(), n_up,
+                               d.mig_caps, d.w.ptr, d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, d.recvbuf.ptr, d.x2.ptr, d.v2.ptr,
+                               d.at2.ptr, d.gid2.ptr);
+            // ---- 3. ghosts: which neighbours need which of my (new) atoms -- their number is a device word
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
+            const int n_sel = d.geo.ghost_nbins > 0 ? n_up : 0, nb2 = std::max(1, d.geo.ghost_nbins);
+            const int nblk2 = partition_prepare(d, n_sel, nb2);
+            if (n_sel > 0)
+                hipLaunchKernelGGL((k_dd_ghost_mask<real>), dim3(nblk2), dim3(PART_BLOCK), 0, d.stream(), n_sel, d.x2.ptr,
+                                   d.geo.template device<real>(), d.mask.ptr, nb2, nblk2, d.counts.ptr, d.w.ptr + DDW_NNEW);
+            DdBins pb{};
+            pb.npeers = np;
+            for (int p = 0; p <= np + 1; p++) pb.lo[p] = d.geo.peer_bin_lo[std::min(p, np)];
+            partition_finish(d, nb2, nblk2, pb);
+            if (n_sel > 0)
+                hipLaunchKernelGGL(k_part_scatter, dim3(nblk2), dim3(PART_BLOCK), 0, d.stream(), n_sel, d.mask.ptr, nb2, nblk2,
+                                   d.counts.ptr, d.ids.ptr, d.bins.ptr, d.w.ptr + DDW_NNEW, d.gs_caps.start[np]);
+            const int nt = std::max(1, std::max(np, d.gs_caps.start[np]));
+            hipLaunchKernelGGL((k_dd_pack_ghost_rows_padded<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.gs_caps,
+                               d.small.ptr + 33, d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), d.x2.ptr, d.at2.ptr,
+                               d.sendbuf.ptr, d.codes.ptr, d.w.ptr);
+            for (int p = 0; p < np; p++) {
+                d.xf.soff[p] = dd_pad_msg_begin(d.gs_caps, p, grow); d.xf.sbytes[p] = dd_pad_msg_bytes(d.gs_caps, p, grow);
+                d.xf.roff[p] = dd_pad_msg_begin(d.gr_caps, p, grow); d.xf.rbytes[p] = dd_pad_msg_bytes(d.gr_caps, p, grow);
+            }
+            d.xf.send = d.sendbuf.ptr;
+            d.xf.recv = d.recvbuf.ptr;
+            record_packed(d);
+        }
+        exchange();
+        wait_exchange();
+        bool over = false;
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            hipLaunchKernelGGL((k_dd_ghost_counts<real>), dim3(1), dim3(64), 0, d.stream(), d.gs_caps, d.gr_caps, d.small.ptr + 33,
+                               d.recvbuf.ptr, d.w.ptr);
+            read_back_words(d.ctx, d.stream(), d.w.ptr, DDW_COUNT, d.host_w);
+            EMDEE_REQUIRE(d.host_w[DDW_ERR] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom of domain %d left the neighbourhood of its brick", d.geo.rank);
+            over = over || d.host_w[DDW_OVER] != 0;
+        }
+        if (over) return false;                                // (the same word on every rank: see k_dd_ghost_counts)
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            const int np = d.geo.npeers;
+            d.x.swap(d.x2); d.v.swap(d.v2); d.at.swap(d.at2); d.gid.swap(d.gid2);
+            d.n_owned = d.host_w[DDW_NNEW];
+            stat_migrated += d.host_w[DDW_NLEAVE];
+            d.plan = DdPlan{};
+            d.plan.npeers = np;
+            for (int p = 0; p < np; p++) {
+                d.plan.send_start[p + 1] = d.plan.send_start[p] + d.host_w[DDW_GSEND + p];
+                d.plan.recv_start[p + 1] = d.plan.recv_start[p] + d.host_w[DDW_GRECV + p];
+            }
+            d.n_send = d.plan.send_start[np];
+            d.n_ghost = d.plan.recv_start[np];
+            EMDEE_REQUIRE(d.n_send == d.host_w[DDW_NSEND] && d.n_ghost == d.host_w[DDW_NGHOST], EMDEE_ERR_STATE, "emdee_dd: ghost counts inconsistent");
+            if (d.n_ghost > 0)
+                hipLaunchKernelGGL((k_dd_unpack_ghost_rows_padded<real>), dim3(blocks_for(d.n_ghost, 256)), dim3(256), 0, d.stream(),
+                                   d.n_ghost, d.plan, d.gr_caps, d.recvbuf.ptr, d.x.ptr + 3 * (size_t)d.n_owned, d.at.ptr + d.n_owned);
+            load_engine(d, with_forces);
+        }
+        stat_rebuilds++;
+        stat_fast++;
+        return true;
     }
 
     static void grow_keep(DevBuf<real> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
@@ -787,10 +948,15 @@ struct DdImpl : IDd {
     bool read_global_words(int first, int count, int *out) {
         // identical on every domain by construction: read the first local one (debug builds could compare)
         Domain<real> &d = *dom[0];
-        EMDEE_HIP_CHECK(hipMemcpyAsync(d.ctx->host_flags, d.G(first), count * sizeof(int), hipMemcpyDeviceToHost, d.stream()));
-        for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
+        if (dom.size() == 1) {
+            read_back_words(d.ctx, d.stream(), d.G(first), count, out);
+        } else {
+            EMDEE_HIP_CHECK(hipMemcpyAsync(d.ctx->host_flags, d.G(first), count * sizeof(int), hipMemcpyDeviceToHost, d.stream()));
+            for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
+            for (int k = 0; k < count; k++) out[k] = d.ctx->host_flags[k];
+        }
         bool any = false;
-        for (int k = 0; k < count; k++) { out[k] = d.ctx->host_flags[k]; any = any || out[k] != 0; }
+        for (int k = 0; k < count; k++) any = any || out[k] != 0;
         return any;
     }
 
@@ -804,6 +970,26 @@ struct DdImpl : IDd {
             redistribute(true);
             if (bitmask != EMDEE_FORCES)
                 for (auto &pd : dom) pd->md->forces(bitmask, 0);
+        }
+    }
+
+    // The inner step that follows a rebuild in the middle of a run, at the positions the rebuild sorted: ONE fused launch
+    // over all bricks (force + kick + drift; the ghosts are fresh, nobody is waited for), which raises V[0] for the positions
+    // it produces -- where round 2 ran a force pass and a separate kick + drift (19 us more per rebuild of a 1.26 M-atom
+    // rank, and two fills).  Domains on the direct kernels keep the split form.
+    void step_after_rebuild(double dt) {
+        for (auto &pd : dom) {
+            Domain<real> &d = *pd;
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            if (d.sys().n_total > 0) {
+                const bool tiled = d.sys().brick_active && !(d.md->current_mask & EMDEE_FORCES) &&
+                                   d.sys().fused_step(dt, dt, 0, nullptr, d.V(0), false, false);
+                if (!tiled) {
+                    if (!(d.md->current_mask & EMDEE_FORCES)) d.md->forces(EMDEE_FORCES, 0);
+                    d.sys().kick_drift(dt, dt, d.V(0));
+                }
+            }
+            d.md->current_mask = 0;
         }
     }
 
@@ -832,13 +1018,9 @@ struct DdImpl : IDd {
             else B = std::max(1, std::min(B, last_interval > 0 ? last_interval - dom[0]->since_build - 1 : 2));
             if (rebuild_every > 0 && dom[0]->since_build + 1 >= rebuild_every) {
                 // fixed cadence: rebuild at the current positions, then the un-fused equivalent of one inner step
-                redistribute(true);
-                for (auto &pd : dom) {
-                    EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
-                    pd->sys().kick_drift(dt, dt, pd->V(0));
-                    pd->md->current_mask = 0;
-                    pd->since_build = 0;
-                }
+                redistribute(true, false);
+                step_after_rebuild(dt);
+                for (auto &pd : dom) pd->since_build = 0;
                 carry = 0;
                 s++;
                 continue;
@@ -889,13 +1071,9 @@ struct DdImpl : IDd {
                 // the positions of step s were flagged: rebuild there (evaluates the forces), then the un-fused
                 // equivalent of that inner step
                 last_interval = dom[0]->since_build;          // steps the list just retired has served
-                redistribute(true);
+                redistribute(true, s >= nsteps);
                 if (s < nsteps) {
-                    for (auto &pd : dom) {
-                        EMDEE_HIP_CHECK(hipMemsetAsync(pd->words.ptr, 0, DD_WORDS * sizeof(int), pd->stream()));
-                        pd->sys().kick_drift(dt, dt, pd->V(0));
-                        pd->md->current_mask = 0;
-                    }
+                    step_after_rebuild(dt);
                     carry = 0;
                     s++;
                 }
@@ -954,6 +1132,11 @@ struct DdImpl : IDd {
     }
     void stats(int64_t out[4]) override {
         out[0] = stat_rebuilds; out[1] = stat_batches; out[2] = stat_cancelled; out[3] = stat_migrated;
+    }
+    void rebuild_stats(int64_t out[4]) override {
+        out[0] = stat_fast + stat_fallback; out[1] = stat_fallback;
+        out[2] = dom.empty() || dom[0]->geo.npeers == 0 ? 0 : dom[0]->mig_caps.start[1];
+        out[3] = dom.empty() ? 0 : dom[0]->gs_caps.start[dom[0]->geo.npeers];
     }
     void set_overlap(bool on) override {
         for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));

@@ -105,11 +105,14 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_classify(int n, real *__restr
 }
 
 // Which neighbours need this owned atom as a ghost: bit dir_bin[k] for every direction k whose halo holds it.
+// (n_dev, optional: the number of items as a device word -- a count-free rebuild launches over an upper bound)
 template <typename real>
 __global__ __launch_bounds__(PART_BLOCK) void k_dd_ghost_mask(int n, const real *__restrict__ x, DdDev<real> g, unsigned *__restrict__ mask,
-                                                              int nbins, int nblocks, int *__restrict__ counts) {
+                                                              int nbins, int nblocks, int *__restrict__ counts,
+                                                              const int *__restrict__ n_dev = nullptr) {
     const int i = blockIdx.x * PART_BLOCK + threadIdx.x;
     unsigned m = 0;
+    if (n_dev) n = min(n, *n_dev);
     if (i < n) {
         bool near_lo[3], near_hi[3];
 #pragma unroll
@@ -134,9 +137,11 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_ghost_mask(int n, const real 
 
 static __global__ __launch_bounds__(PART_BLOCK) void k_part_scatter(int n, const unsigned *__restrict__ mask, int nbins,
                                                                     int nblocks, const int *__restrict__ offs,
-                                                                    int *__restrict__ out_id, int *__restrict__ out_bin) {
+                                                                    int *__restrict__ out_id, int *__restrict__ out_bin,
+                                                                    const int *__restrict__ n_dev = nullptr, int out_cap = 0x7fffffff) {
     __shared__ int wc[PART_BLOCK / WAVE][32];
     const int i = blockIdx.x * PART_BLOCK + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     const unsigned m = i < n ? mask[i] : 0u;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     for (int b = 0; b < nbins; b++) {
@@ -150,8 +155,10 @@ static __global__ __launch_bounds__(PART_BLOCK) void k_part_scatter(int n, const
             int pos = offs[(size_t)b * nblocks + blockIdx.x];
             for (int w = 0; w < wv; w++) pos += wc[w][b];
             pos += prefix_popc(bal);
-            out_id[pos] = i;
-            if (out_bin) out_bin[pos] = b;
+            if (pos < out_cap) {                               // (a count-free rebuild whose lists outgrew their capacity is redone)
+                out_id[pos] = i;
+                if (out_bin) out_bin[pos] = b;
+            }
         }
     }
 }
@@ -233,6 +240,175 @@ __global__ void k_dd_unpack_ghost_rows(int n, const GhostRow<real> *__restrict__
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const GhostRow<real> r = rows[k];
+#pragma unroll
+    for (int d = 0; d < 3; d++) x[3 * (size_t)k + d] = r.x[d];
+    emdee_lj_atom a;
+    a.half_sigma = r.hs; a.twice_sqrt_eps = r.te;
+    atoms[k] = a;
+}
+
+// ------------------------------------------------------------------------------------ count-free rebuild messages
+// Round 2 exchanged the row counts of a migration and of a ghost selection first (two extra RCCL groups and two blocking
+// read-backs per rebuild) because the counts size the messages.  Here a message has a CAPACITY both ends know without
+// talking -- migrants: a fixed number of rows per peer; ghost rows: the count of the previous rebuild plus an eighth --
+// and starts with a 16-byte header {rows, overflow, 0, 0}; everything between the two exchanges runs on device-side
+// counts over upper-bound grids, and ONE read-back at the end tells the host all of them.  "overflow" is raised in ALL
+// messages of a rank whose rows for some peer exceed the capacity; every rank neighbours every other one, so everybody
+// learns of it in the same exchange and the whole rebuild is redone with exact counts (dd.hpp).
+constexpr int DD_RHDR = 16;
+struct DdCaps {
+    int npeers;
+    int start[DD_MAX_PEERS + 1];       // rows: message p holds slots [start[p], start[p+1]) of the padded buffer
+};
+__host__ __device__ static inline size_t dd_pad_begin(const DdCaps &c, int p, size_t row) { return (size_t)(p + 1) * DD_RHDR + (size_t)c.start[p] * row; }
+static inline size_t dd_pad_msg_begin(const DdCaps &c, int p, size_t row) { return (size_t)p * DD_RHDR + (size_t)c.start[p] * row; }
+static inline size_t dd_pad_msg_bytes(const DdCaps &c, int p, size_t row) { return DD_RHDR + (size_t)(c.start[p + 1] - c.start[p]) * row; }
+static inline size_t dd_pad_total(const DdCaps &c, size_t row) { return (size_t)c.npeers * DD_RHDR + (size_t)c.start[c.npeers] * row; }
+
+__device__ __forceinline__ int dd_caps_peer(const DdCaps &c, int t) {
+    int p = 0;
+    while (p + 1 < c.npeers && t >= c.start[p + 1]) p++;
+    return p;
+}
+
+// words a count-free rebuild leaves for its one read-back (ints)
+constexpr int DDW_NSTAY = 0, DDW_NNEW = 1, DDW_ERR = 2, DDW_OVER = 3, DDW_NLEAVE = 4, DDW_NARRIVE = 5, DDW_NSEND = 6, DDW_NGHOST = 7,
+              DDW_GSEND = 8, DDW_GRECV = 8 + DD_MAX_PEERS, DDW_ARRIVE = 8 + 2 * DD_MAX_PEERS, DDW_COUNT = 8 + 3 * DD_MAX_PEERS;
+
+// leavers -> padded messages (ids[bin_start[1 + p] + slot], the stable partition's order); headers
+template <typename real>
+__global__ void k_dd_pack_migrants_padded(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ ids,
+                                          const real *__restrict__ x, const real *__restrict__ v,
+                                          const emdee_lj_atom *__restrict__ atoms, const long long *__restrict__ gid,
+                                          unsigned char *__restrict__ buf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < caps.npeers) {
+        int over = 0;
+        for (int q = 0; q < caps.npeers; q++) over |= (bin_start[2 + q] - bin_start[1 + q]) > (caps.start[q + 1] - caps.start[q]);
+        int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(MigRow<real>)) - DD_RHDR);
+        hdr[0] = bin_start[2 + t] - bin_start[1 + t]; hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
+    }
+    if (t >= caps.start[caps.npeers]) return;
+    const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
+    if (slot >= bin_start[2 + p] - bin_start[1 + p]) return;
+    const int i = ids[bin_start[1 + p] + slot];
+    MigRow<real> r;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { r.x[d] = x[3 * (size_t)i + d]; r.v[d] = v[3 * (size_t)i + d]; }
+    r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
+    r.gid = gid[i];
+    reinterpret_cast<MigRow<real> *>(buf + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[slot] = r;
+}
+
+// after the migrant exchange: w[DDW_NSTAY], w[DDW_NNEW], arrivals per peer, overflow (mine or anybody's), error word
+template <typename real>
+__global__ void k_dd_migrant_counts(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ err,
+                                    const unsigned char *__restrict__ recv, int *__restrict__ w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int over = 0, arrive = 0, leave = 0;
+    for (int p = 0; p < caps.npeers; p++) {
+        const int cap = caps.start[p + 1] - caps.start[p];
+        const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)) - DD_RHDR);
+        const int out = bin_start[2 + p] - bin_start[1 + p];
+        over |= hdr[1] | (hdr[0] > cap) | (out > cap);
+        const int in = min(max(hdr[0], 0), cap);
+        w[DDW_ARRIVE + p] = in;
+        arrive += in; leave += out;
+    }
+    w[DDW_NSTAY] = bin_start[1];
+    w[DDW_NNEW] = bin_start[1] + arrive;
+    w[DDW_ERR] = *err;
+    w[DDW_OVER] = over;
+    w[DDW_NLEAVE] = leave;
+    w[DDW_NARRIVE] = arrive;
+}
+
+// new owned arrays from device-side counts: stayers (ids[0 .. n_stay)), then the arrivals in peer order
+template <typename real>
+__global__ void k_dd_assemble_padded(int n_max, DdCaps caps, const int *__restrict__ w, const int *__restrict__ ids,
+                                     const real *__restrict__ x, const real *__restrict__ v, const emdee_lj_atom *__restrict__ atoms,
+                                     const long long *__restrict__ gid, const unsigned char *__restrict__ recv,
+                                     real *__restrict__ x2, real *__restrict__ v2, emdee_lj_atom *__restrict__ atoms2,
+                                     long long *__restrict__ gid2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_stay = w[DDW_NSTAY], n_new = min(w[DDW_NNEW], n_max);
+    if (k >= n_new) return;
+    if (k < n_stay) {
+        const int i = ids[k];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { x2[3 * (size_t)k + d] = x[3 * (size_t)i + d]; v2[3 * (size_t)k + d] = v[3 * (size_t)i + d]; }
+        atoms2[k] = atoms[i];
+        gid2[k] = gid[i];
+        return;
+    }
+    int a = k - n_stay, p = 0;
+    while (p + 1 < caps.npeers && a >= w[DDW_ARRIVE + p]) { a -= w[DDW_ARRIVE + p]; p++; }
+    const MigRow<real> r = reinterpret_cast<const MigRow<real> *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[a];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { x2[3 * (size_t)k + d] = r.x[d]; v2[3 * (size_t)k + d] = r.v[d]; }
+    emdee_lj_atom at;
+    at.half_sigma = r.hs; at.twice_sqrt_eps = r.te;
+    atoms2[k] = at;
+    gid2[k] = r.gid;
+}
+
+// ghost rows -> padded messages; peer_count[p] = entries bound for peer p (k_part_starts), list entry k of peer p sits at
+// sum of the counts before p + slot; codes[k] = direction, for the per-step messages
+template <typename real>
+__global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__ peer_count, const int *__restrict__ ids,
+                                            const int *__restrict__ bins, DdDev<real> g, const real *__restrict__ x,
+                                            const emdee_lj_atom *__restrict__ atoms, unsigned char *__restrict__ buf,
+                                            int *__restrict__ codes, const int *__restrict__ w_over) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < caps.npeers) {
+        int over = w_over[DDW_OVER];
+        for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
+        int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(GhostRow<real>)) - DD_RHDR);
+        hdr[0] = peer_count[t]; hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
+    }
+    if (t >= caps.start[caps.npeers]) return;
+    const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
+    if (slot >= peer_count[p]) return;
+    int k = slot;
+    for (int q = 0; q < p; q++) k += peer_count[q];
+    const int i = ids[k], dir = g.bin_dir[bins[k]];
+    GhostRow<real> r;
+#pragma unroll
+    for (int d = 0; d < 3; d++) r.x[d] = x[3 * (size_t)i + d] + g.shift[dir][d];
+    r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
+    reinterpret_cast<GhostRow<real> *>(buf + dd_pad_begin(caps, p, sizeof(GhostRow<real>)))[slot] = r;
+    codes[k] = dir;
+}
+
+// after the ghost exchange: send / receive counts per peer, totals, overflow of either exchange
+template <typename real>
+__global__ void k_dd_ghost_counts(DdCaps scaps, DdCaps rcaps, const int *__restrict__ peer_count,
+                                  const unsigned char *__restrict__ recv, int *__restrict__ w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int over = w[DDW_OVER], nsend = 0, nghost = 0;
+    for (int p = 0; p < scaps.npeers; p++) {
+        const int rcap = rcaps.start[p + 1] - rcaps.start[p], scap = scaps.start[p + 1] - scaps.start[p];
+        const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
+        over |= hdr[1] | (hdr[0] > rcap) | (peer_count[p] > scap);
+        w[DDW_GSEND + p] = peer_count[p];
+        w[DDW_GRECV + p] = hdr[0];
+        nsend += peer_count[p];
+        nghost += hdr[0];
+    }
+    w[DDW_OVER] = over;
+    w[DDW_NSEND] = nsend;
+    w[DDW_NGHOST] = nghost;
+}
+
+// padded ghost messages -> the ghosts behind the owned atoms (recv_start: prefix of the receive counts, now known)
+template <typename real>
+__global__ void k_dd_unpack_ghost_rows_padded(int n, DdPlan plan, DdCaps rcaps, const unsigned char *__restrict__ recv,
+                                              real *__restrict__ x, emdee_lj_atom *__restrict__ atoms) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int p = 0;
+    while (p + 1 < plan.npeers && k >= plan.recv_start[p + 1]) p++;
+    const GhostRow<real> r = reinterpret_cast<const GhostRow<real> *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)))[k - plan.recv_start[p]];
 #pragma unroll
     for (int d = 0; d < 3; d++) x[3 * (size_t)k + d] = r.x[d];
     emdee_lj_atom a;

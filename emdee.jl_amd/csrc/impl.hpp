@@ -152,10 +152,15 @@ struct MdImpl : IMd {
         n_ghost = ng;
         sys.load_user(n_owned, ng, (const real *)pos, (const real *)vel, atoms, (const real *)inv_mass);
         since_build = 0;
-        sys.compute_forces(EMDEE_FORCES);
-        current_mask = EMDEE_FORCES;
+        current_mask = 0;
+        if (!defer_forces) {
+            sys.compute_forces(EMDEE_FORCES);
+            current_mask = EMDEE_FORCES;
+        }
         EMDEE_HIP_CHECK(hipGetLastError());
     }
+    // emdee_dd_step: the rebuild in the middle of a run is followed by a fused step, which evaluates the forces itself
+    bool defer_forces = false;
     void get_state(void *pos, void *vel, void *frc, void *en, void *vir) override {
         use_device(sys.ctx);
         EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");

@@ -522,8 +522,7 @@ struct NbSystem {
     bool plan_bricks() {
         plan_geometry();
         launch_tile_max();
-        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 6, flags.ptr + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, stream()));
-        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        read_back_words(ctx, stream(), flags.ptr + 6, 3, ctx->host_flags + 6);
         for (int k = 0; k < 3; k++) plan_maxima[k] = ctx->host_flags[6 + k];
         return plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]);
     }
@@ -742,8 +741,7 @@ struct NbSystem {
             }
             // a build is rare (every ~7 steps): one blocking read-back -- the overflow words and, under a kept plan, the
             // population maxima it has to hold for
-            EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags, flags.ptr, 9 * sizeof(int), hipMemcpyDeviceToHost, stream()));
-            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+            read_back_words(ctx, stream(), flags.ptr, 9, ctx->host_flags);
             if (kept && (!plan_holds(ctx->host_flags + 6) || ctx->host_flags[2] != 0)) {
                 // the populations outgrew the kept plan (the kernels skipped the bricks concerned): plan afresh and build again
                 kept = false;
@@ -939,8 +937,7 @@ struct NbSystem {
             swap_step_buffers();
         }
         step_trigger = nullptr; step_guard = nullptr;
-        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 9, words, B * sizeof(int), hipMemcpyDeviceToHost, stream()));
-        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        read_back_words(ctx, stream(), words, B, ctx->host_flags + 9);
         int ran = B;
         for (int i = 0; i < B; i++)
             if (ctx->host_flags[9 + i]) { ran = i + 1; *stale = true; break; }
@@ -1016,8 +1013,7 @@ struct NbSystem {
 
     // blocking read of the rebuild trigger raised by kick_drift / check_user_displacement
     bool read_rebuild_flag() {
-        EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 1, flags.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
-        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        read_back_words(ctx, stream(), flags.ptr + 1, 1, ctx->host_flags + 1);
         return ctx->host_flags[1] != 0;
     }
 

@@ -77,3 +77,11 @@ set_langevin!(dd::DomainDecomposition, gamma, temperature; seed=0, first_step=0)
 # true (default): interior bricks overlap the halo exchange; false: exchange and one launch over all bricks in order
 set_overlap!(dd::DomainDecomposition, on::Bool) =
     check(ccall((:emdee_dd_set_overlap, libemdee_hip), Int32, (Ptr{Cvoid}, Int32), dd.handle, on ? 1 : 0))
+
+# int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]);
+# (count-free rebuilds, those redone with exact counts, migrant rows per message, ghost rows the messages hold)
+function rebuild_stats(dd::DomainDecomposition)
+    out = zeros(Int64, 4)
+    check(ccall((:emdee_dd_rebuild_stats, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Int64}), dd.handle, out))
+    (count_free = out[1], redone = out[2], migrant_rows_per_peer = out[3], ghost_rows_capacity = out[4])
+end

@@ -305,6 +305,11 @@ int32_t emdee_dd_set_langevin(emdee_dd *dd, double gamma, double temperature, ui
 /* out[0] = rebuilds, out[1] = batches of queued steps, out[2] = queued steps cancelled by a rebuild request,
  * out[3] = atoms that changed owner (this process) */
 int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]);
+/* How the rebuilds of this process went: out[0] = rebuilds whose migrant and ghost rows travelled in capacity-padded
+ * messages with no count exchange (one read-back), out[1] = of those, the ones redone with exact counts because a
+ * capacity was exceeded on some rank, out[2] = migrant rows a message holds per peer, out[3] = ghost rows the messages
+ * of local domain 0 hold in all (send side). */
+int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]);
 /* How a step meets its halo exchange.  1 (default): interior bricks while the messages travel on a communication stream,
  * boundary bricks on a stream of their own when they have arrived.  0: pack, exchange, unpack and ONE launch over all
  * bricks, in order on the compute stream -- no events, no split launch; cheaper when the messages are short next to the
