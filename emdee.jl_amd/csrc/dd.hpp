@@ -247,6 +247,9 @@ struct DdImpl : IDd {
     bool two_streams = true;              // EMDEE_DD_STREAMS=1: interior and boundary launches on one stream
     bool no_shortcut = false;             // EMDEE_DD_NO_SHORTCUT=1: a one-domain grid goes through the whole ownership path (profiling)
     bool count_free = true;               // EMDEE_DD_COUNT_FREE=0: every rebuild exchanges its row counts first (round 2)
+    bool lockstep = true;                 // EMDEE_DD_LOCKSTEP=0: the overlapped form on three streams (round 2)
+    bool halo_live = false;               // the halo stream holds work the compute stream has not waited for yet
+    int mig_cap_forced = 0;               // EMDEE_DD_MIG_CAP=n: migrant rows per message (tests: 1 forces the redo with counts)
     int64_t stat_fast = 0, stat_fallback = 0;
     int last_interval = 0;
     // Langevin
@@ -292,6 +295,8 @@ struct DdImpl : IDd {
         if (const char *e = std::getenv("EMDEE_DD_STREAMS")) two_streams = std::atoi(e) != 1;
         if (const char *e = std::getenv("EMDEE_DD_NO_SHORTCUT")) no_shortcut = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_COUNT_FREE")) count_free = std::atoi(e) != 0;
+        if (const char *e = std::getenv("EMDEE_DD_LOCKSTEP")) lockstep = std::atoi(e) != 0;
+        if (const char *e = std::getenv("EMDEE_DD_MIG_CAP")) mig_cap_forced = std::max(1, std::atoi(e));
         for (int l = 0; l < n_local; l++) {
             dom.push_back(std::make_unique<Domain<real>>());   // registered first: release() sees whatever it gets below
             Domain<real> *d = dom.back().get();
@@ -368,7 +373,8 @@ struct DdImpl : IDd {
     // step).  Several domains in one process copy from each other's buffers and keep the events.
     // The exchanges of a rebuild (counts, migrants, ghost rows) have nothing to overlap with and always go in order.
     bool in_rebuild = false;
-    bool inline_exchange() const { return (!overlap || in_rebuild) && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0); }
+    bool force_inline = false;            // (lock-step halves: the exchange is queued on whatever stream the domain points at)
+    bool inline_exchange() const { return (!overlap || in_rebuild || force_inline) && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0); }
     void record_packed(Domain<real> &d) {
         if (!inline_exchange()) EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
     }
@@ -599,6 +605,7 @@ struct DdImpl : IDd {
             explicit Scope(bool &b) : f(b) { f = true; }
             ~Scope() { f = false; }
         } scope(in_rebuild);
+        join_halo();
         if (world == 1 && from_engines && !no_shortcut) {
             // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
             // none of the ownership passes and their two count read-backs)
@@ -725,7 +732,7 @@ struct DdImpl : IDd {
         const int np = d.geo.npeers;
         const int64_t per_rank = n_global > 0 ? n_global / world : (int64_t)d.n_owned;
         int mig = (int)std::max<int64_t>(256, per_rank / 512);
-        if (const char *e = std::getenv("EMDEE_DD_MIG_CAP")) mig = std::max(1, std::atoi(e));   // tests: force the fallback
+        if (mig_cap_forced > 0) mig = mig_cap_forced;
         d.mig_caps.npeers = d.gs_caps.npeers = d.gr_caps.npeers = np;
         d.mig_caps.start[0] = d.gs_caps.start[0] = d.gr_caps.start[0] = 0;
         for (int p = 0; p < np; p++) {
@@ -881,8 +888,67 @@ struct DdImpl : IDd {
 
     // ---------------------------------------------------------------- one halo exchange around a compute call
     // pack (request word = *V) -> exchange || compute(1) -> unpack (G |= requests) -> compute(2)
+    // The overlapped form of one process = one domain, in LOCK STEP on two streams (round 3).  Round 2 sent a step through
+    // three streams -- pack on the compute stream, the messages on a communication stream, unpack + boundary bricks on a
+    // third -- i.e. three event hops on the critical path of every step (pack -> messages -> boundary half -> next pack),
+    // each ~10 us of empty queue: the overlapped form lost to the in-order one on every one-GPU rehearsal.  Here the whole
+    // halo half of a step -- pack, ncclSend/ncclRecv, unpack, boundary bricks -- is queued IN ORDER on the halo stream, the
+    // interior bricks on the compute stream, and the two meet once per step: the halo half waits for what the compute
+    // stream had produced when the step began (interior launch of the previous step: positions, its rebuild request word;
+    // the thermostat's noise), the interior launch for the boundary half of the previous step.  Two records and two waits,
+    // one hop on the critical path.
+    bool lockstep_ok() const {
+        return overlap && two_streams && lockstep && !in_rebuild && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0);
+    }
+    // the compute stream catches up with the halo stream (before a read-back, a rebuild, anything that is not a step)
+    void join_halo() {
+        if (!halo_live) return;
+        EMDEE_HIP_CHECK(hipStreamWaitEvent(dom[0]->ctx->stream, dom[0]->ev_bnd, 0));
+        halo_live = false;
+    }
+    template <class F>
+    void with_halo_lockstep(int vj, int gj, F &&compute) {
+        const size_t w = sizeof(real);
+        Domain<real> &d = *dom[0];
+        hipStream_t main_stream = d.ctx->stream;
+        EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, main_stream));           // everything up to the previous interior launch
+        if (halo_live) EMDEE_HIP_CHECK(hipStreamWaitEvent(main_stream, d.ev_bnd, 0));   // boundary half of the previous step
+        compute(d, 1);
+        struct Restore {
+            emdee_ctx *ctx;
+            hipStream_t keep;
+            bool &flag;
+            ~Restore() { ctx->stream = keep; flag = false; }
+        } restore{d.ctx, main_stream, force_inline};
+        d.ctx->stream = d.side;
+        force_inline = true;
+        EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_packed, 0));
+        const int np = d.geo.npeers;
+        hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(std::max(d.n_send, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
+                           d.n_send, d.plan, d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr,
+                           d.V(vj), d.sendbuf.ptr);
+        for (int p = 0; p < np; p++) {
+            d.xf.soff[p] = dd_msg_begin(d.plan.send_start, p, w); d.xf.sbytes[p] = dd_msg_bytes(d.plan.send_start, p, w);
+            d.xf.roff[p] = dd_msg_begin(d.plan.recv_start, p, w); d.xf.rbytes[p] = dd_msg_bytes(d.plan.recv_start, p, w);
+        }
+        d.xf.send = d.sendbuf.ptr;
+        d.xf.recv = d.recvbuf.ptr;
+        exchange();                                                        // in order on the halo stream
+        hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(std::max(d.n_ghost, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
+                           d.n_ghost, d.n_owned, d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
+        d.md->current_mask = 0;
+        compute(d, 2);
+        EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
+        halo_live = true;
+    }
+
     template <class F>
     void with_halo(int vj, int gj, F &&compute) {
+        if (lockstep_ok()) {
+            with_halo_lockstep(vj, gj, compute);
+            return;
+        }
+        join_halo();
         const size_t w = sizeof(real);
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
@@ -948,6 +1014,7 @@ struct DdImpl : IDd {
     bool read_global_words(int first, int count, int *out) {
         // identical on every domain by construction: read the first local one (debug builds could compare)
         Domain<real> &d = *dom[0];
+        join_halo();
         if (dom.size() == 1) {
             read_back_words(d.ctx, d.stream(), d.G(first), count, out);
         } else {
@@ -965,6 +1032,7 @@ struct DdImpl : IDd {
     void forces_with_halo(int bitmask, int carry, bool check_displacement = true) {
         for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
         with_halo(0, 0, [&](Domain<real> &d, int phase) { d.md->forces(bitmask, phase); });
+        join_halo();
         int g = 0;
         if (check_displacement && read_global_words(0, 1, &g)) {
             redistribute(true);
@@ -1027,6 +1095,7 @@ struct DdImpl : IDd {
             }
             for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
             for (int j = 0; j < B; j++) {
+                if (lgv_on) join_halo();   // (the boundary half of the previous step still reads the previous noise)
                 for (auto &pd : dom)
                     if (pd->sys().brick_active) pd->sys().prepare_noise(dt);   // (thermostat only) before the pack: both halves read it
                 with_halo(j, j, [&](Domain<real> &d, int phase) {
@@ -1044,6 +1113,7 @@ struct DdImpl : IDd {
                     }
                 });
             }
+            join_halo();
             int g[DD_MAX_BATCH];
             int ran = B;
             stat_batches++;
@@ -1079,6 +1149,7 @@ struct DdImpl : IDd {
                 }
             }
         }
+        join_halo();
         // ---- last step: plain force pass and the closing half kick
         if (dom[0]->md->current_mask & EMDEE_FORCES) {
             // (a rebuild at the last positions has just evaluated them)
@@ -1099,6 +1170,7 @@ struct DdImpl : IDd {
     void energies(double out[3]) override {
         use_device(user_ctx);
         EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_energies: call emdee_dd_load first");
+        join_halo();
         std::vector<std::vector<double>> vals;
         for (auto &pd : dom) {
             // ghosts are current whenever the forces are (every force pass follows a halo unpack or a rebuild)
@@ -1116,6 +1188,7 @@ struct DdImpl : IDd {
         use_device(user_ctx);
         Domain<real> &d = local(l);
         EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_get_state: call emdee_dd_load first");
+        join_halo();
         const size_t n = (size_t)d.n_owned;
         d.f.ensure(3 * n + 3);
         // caller-order copies of the whole domain (positions include the ghosts) into scratch, owned part out
@@ -1139,6 +1212,7 @@ struct DdImpl : IDd {
         out[3] = dom.empty() ? 0 : dom[0]->gs_caps.start[dom[0]->geo.npeers];
     }
     void set_overlap(bool on) override {
+        join_halo();
         for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamSynchronize(pd->stream()));
         overlap = on;
     }

@@ -117,6 +117,44 @@ def test_dd_in_order_exchange_gives_the_same_trajectory(emdee, world):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("world,dtype", [(8, "f64"), (3, "f64"), (4, "f32"), (1, "f64")])
+def test_dd_count_free_rebuilds_give_the_same_trajectory(emdee, world, dtype, monkeypatch):
+    """Rebuilds after the first two send migrants and ghost rows in capacity-padded messages with NO count exchange and one
+    read-back (emdee_dd_rebuild_stats); the states must be bitwise those of the rebuilds that exchange their counts first
+    (EMDEE_DD_COUNT_FREE=0) -- and stay so when a capacity is exceeded (one migrant row per message: every rank sees the
+    overflow in the headers it receives and the rebuild is redone with counts)."""
+    E = emdee
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform=(world == 8))
+    vel = 1.6 * vel                                  # hot: rebuilds every few steps, atoms change owner at most of them
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    monkeypatch.setenv("EMDEE_DD_NO_SHORTCUT", "1")  # (a one-domain grid goes through the ownership path too)
+    runs = {}
+    for name, env in (("counts", {"EMDEE_DD_COUNT_FREE": "0"}), ("free", {}), ("overflow", {"EMDEE_DD_MIG_CAP": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dd = _build(E, world, pos, vel, atoms, L, dtype=tdt)
+        for k in env:
+            monkeypatch.delenv(k)
+        dd.step_(17, DT, 0)
+        dd.step_(15, DT, 3)
+        runs[name] = _gather(dd, world, N) + (dd.stats(), dd.rebuild_stats(), dd.totals())
+        dd.close()
+    xc, vc, fc, sc, rc, ec = runs["counts"]
+    assert rc["count_free"] == 0 and sc["rebuilds"] >= 6
+    for name in ("free", "overflow"):
+        x, v, f, st, rs, e = runs[name]
+        assert np.array_equal(x, xc) and np.array_equal(v, vc) and np.array_equal(f, fc), name
+        assert st["rebuilds"] == sc["rebuilds"] and st["migrated"] == sc["migrated"] and e == ec
+        # everything after the load and the first rebuild from the engines (which fixes the capacities) is count-free
+        assert rs["count_free"] >= sc["rebuilds"] - 2 > 0
+    assert runs["free"][4]["redone"] == 0
+    if world > 1:
+        assert sc["migrated"] > N // 4               # (the scattered initial slices, then the hot box)
+        assert runs["overflow"][4]["redone"] > 0 and runs["overflow"][4]["migrant_rows_per_peer"] == 1
+
+
 def test_dd_langevin_single_call_matches_oracle(emdee, oracle):
     """Noise keyed by global atom id and step number: the decomposed run draws what the undivided run draws."""
     E = emdee
