@@ -141,6 +141,12 @@ struct BrickArgs {
     // typed boxes (two species, typed.hpp): per-(cell, species) starts and the pair constants sigma_ij^2, 4 eps_ij, [ti * 2 + tj]
     const int *tstart;
     real tsig2[4], te4[4];
+    // x sub-bins (kernels.hpp XSubBin; untyped boxes): nsub = 4 when the sort orders a cell's atoms by quarter, sub_k = K,
+    // fstart = first slot of every (cell, sub-bin) block, bsub = per brick and tile cell the three inner boundaries of the
+    // cell's sub-bins (10 bits each, relative to the cell's first atom), written by k_brick_tables for the build kernel
+    int nsub, sub_k;
+    const int *fstart;
+    int *bsub;
     const real *user_pos;      // ... read from the CALLER's array (3 x N, caller order): the engine's records hold positions wrapped
                                // into the box, and x - L rounded to fp32 is not the number the reference divides by L
 };
@@ -195,11 +201,16 @@ static inline size_t brick_force_lds_bytes(int tile_cap, int own_cap) {
     return tile_bytes + te_bytes + BrickTables<Shape, THREADS>::bytes(own_cap);
 }
 template <class Shape, int THREADS>
-static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap, int stride, int G) {
+static inline size_t brick_build_lds_bytes(int tile_cap, int own_cap, int stride, int G, int nsub = 1) {
     // + one row buffer (stride uint16) per G-lane group
     // + the candidate rows of every own cell ({first slot, span} of its 9 tile rows, and one all-zero set for ghosts)
+    // (one packed word per row; nsub > 1: one set of rows per own cell AND sub-bin)
     return (size_t)tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * stride * 2 +
-           (size_t)(Shape::NOC + 1) * 9 * 8;
+           (((size_t)(Shape::NOC * nsub + 1) * 9 * 4 + 15) & ~(size_t)15);
+}
+// atoms of a tile cell in sub-bins below s, from its packed boundaries (s <= 0: none, s >= 4: the whole cell)
+__device__ __forceinline__ int sub_below(int packed, int s, int population) {
+    return s <= 0 ? 0 : (s >= 4 ? population : ((packed >> (10 * (s - 1))) & 1023));
 }
 
 // position of the e-th neighbour inside a row: blocks of 8 G entries, lane-major inside a block,
@@ -322,6 +333,14 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         }
         T.gbeg[tid] = gb;
         T.shift[tid] = sh;
+        if (COMPUTE && a.bsub != nullptr) {
+            int packed = 0;
+            if (valid && a.nsub == 4) {
+                const int *fs = a.fstart + 4 * (size_t)(gx + Mx * (gy + My * gz));
+                packed = (fs[1] - gb) | ((fs[2] - gb) << 10) | ((fs[3] - gb) << 20);
+            }
+            a.bsub[(size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * NTC + tid] = packed;
+        }
     }
     {   // exclusive scan of my_cnt over the first NTC threads (NTC <= THREADS)
         int inc = my_cnt;
@@ -456,6 +475,28 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
     int bxi, byi, bzi, tile_n, n_own;
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    // x sub-bins (the two-phase builds that take their candidate rows from the row table): rows per own cell AND sub-bin
+    constexpr bool SUBOK = ALG == 3 || ALG == 5 || ALG == 13 || ALG == 15;
+    const int NSUB = (SUBOK && a.nsub == 4 && a.bsub != nullptr) ? 4 : 1;
+    // (one word per row: first slot | slots << 16 -- a tile holds < 2^16 slots; the build's LDS decides whether a CU takes
+    // three workgroups.  The sub-bin boundaries of the tile cells are only needed until the row table is written: they
+    // borrow the row buffers, which nobody touches before the barrier behind that.)
+    unsigned *rtab = reinterpret_cast<unsigned *>(s_dyn + (size_t)a.tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(a.own_cap) +
+                                                  (size_t)NGROUPS * a.stride * 2);
+    int *s_sub = reinterpret_cast<int *>(s_dyn + (size_t)a.tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(a.own_cap));
+    auto rt_get = [](const unsigned *rt, int r) { const unsigned v = rt[r]; return make_int2((int)(v & 0xffffu), (int)(v >> 16)); };
+    if (NSUB > 1) {
+        const int *bs = a.bsub + (size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * Shape::NTC;
+        for (int i = tid; i < Shape::NTC; i += THREADS) s_sub[i] = bs[i];
+        __syncthreads();
+    }
+    // sub-bin of the own atom at tile slot ti of own cell oc
+    auto own_sub = [&](int oc, int ti) {
+        if (NSUB == 1) return 0;
+        const int tc = (oc % BX + 1) + TX * (((oc / BX) % BY + 1) + TY * (oc / (BX * BY) + 1));
+        const int kk = ti - T.off[tc], pk = s_sub[tc];
+        return (kk >= (pk & 1023) ? 1 : 0) + (kk >= ((pk >> 10) & 1023) ? 1 : 0) + (kk >= ((pk >> 20) & 1023) ? 1 : 0);
+    };
 
     // brick origin: fp64 boxes are re-based here so that fp32 coordinates stay small
     real org[3] = {0, 0, 0};
@@ -496,25 +537,31 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], (own_oc[k] << 20) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
+        if (o < n_own)
+            T.oinfo[o] = make_int2(own_p[k], (own_oc[k] << 20) | (own_sub(own_oc[k], own_ti[k]) << 17) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         const int oc = brick_locate(T, o, ti, p);
-        T.oinfo[o] = make_int2(p, (oc << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+        T.oinfo[o] = make_int2(p, (oc << 20) | (own_sub(oc, ti) << 17) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
-    // candidate rows per own cell: the 9 tile rows (dy, dz) of 3 cells around it, as {first tile slot, slots}; entry NOC
-    // is empty (atoms that own no row).  One table per brick instead of index arithmetic and two reads per atom and row.
-    int2 *rtab = reinterpret_cast<int2 *>(s_dyn + (size_t)a.tile_cap * 16 + BrickTables<Shape, THREADS>::bytes(a.own_cap) +
-                                          (size_t)NGROUPS * a.stride * 2);
-    for (int i = tid; i < (Shape::NOC + 1) * 9; i += THREADS) {
-        const int oc = i / 9, r = i % 9;
-        int2 v = make_int2(0, 0);
-        if (oc < Shape::NOC) {
+    // candidate rows per own cell (and sub-bin): the 9 tile rows (dy, dz) of 3 cells around it, as {first tile slot, slots};
+    // the last entry is empty (atoms that own no row).  One table per brick instead of index arithmetic and two reads per
+    // atom and row.  With x sub-bins (cells sorted by quarter along x) an atom of sub-bin s takes the quarters >= s + K of
+    // the left cell, the whole middle cell and the quarters <= s - K of the right cell: still one run of tile slots.
+    for (int i = tid; i < (Shape::NOC * NSUB + 1) * 9; i += THREADS) {
+        const int ocs = i / 9, r = i % 9;
+        unsigned v = 0;
+        if (ocs < Shape::NOC * NSUB) {
+            const int oc = ocs / NSUB, sb = ocs - oc * NSUB;
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const int tcr = ox + TX * ((oy + r % 3) + TY * (oz + r / 3));       // cell x-1 of tile row (dy, dz) = (r%3-1, r/3-1)
-            v.x = T.off[tcr];
-            v.y = T.off[tcr + 3] - v.x;
+            int first = T.off[tcr], last = T.off[tcr + 3];
+            if (NSUB > 1) {
+                first += sub_below(s_sub[tcr], sb + a.sub_k, T.off[tcr + 1] - T.off[tcr]);
+                last = T.off[tcr + 2] + sub_below(s_sub[tcr + 2], sb - a.sub_k + 1, T.off[tcr + 3] - T.off[tcr + 2]);
+            }
+            v = (unsigned)first | ((unsigned)(last - first) << 16);
         }
         rtab[i] = v;
     }
@@ -582,11 +629,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             const float4 qi = tile[ti];
             unsigned short *row = a.nbr + (size_t)p * a.stride;
             for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
-            const int2 *rt = rtab + (act ? oc : Shape::NOC) * 9;
+            const unsigned *rt = rtab + (act ? oc : Shape::NOC) * 9;
             int trips_of[NROWS];
             {   // wave-uniform trip counts of the nine rows from one reduction (as ALG 13)
-                int cv = (int)((unsigned)(rt[min(gl, NROWS - 1)].y + G - 1) / (unsigned)G);
-                int c8 = (int)((unsigned)(rt[NROWS - 1].y + G - 1) / (unsigned)G);
+                int cv = (int)((unsigned)(rt_get(rt, min(gl, NROWS - 1)).y + G - 1) / (unsigned)G);
+                int c8 = (int)((unsigned)(rt_get(rt, NROWS - 1).y + G - 1) / (unsigned)G);
                 cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
                 c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
                 auto rows_max = [](int v) {
@@ -602,11 +649,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     trips_of[r] = (r == NROWS - 1) ? __builtin_amdgcn_readlane(c8, 0) : __builtin_amdgcn_readlane(cv, r);
             }
             unsigned D[NROWS];                                   // two bits per candidate of my share of each tile row
-            int2 rv_next = rt[0];
+            int2 rv_next = rt_get(rt, 0);
 #pragma unroll
             for (int r = 0; r < NROWS; r++) {
                 const int c0 = rv_next.x, span = rv_next.y;
-                if (r + 1 < NROWS) rv_next = rt[r + 1];
+                if (r + 1 < NROWS) rv_next = rt_get(rt, r + 1);
                 const int lim = (int)((unsigned)(span - gl + G - 1) >> LOG2G);   // my candidates: slots cb + k G, k < lim (may be <= 0)
                 const int cb = c0 + gl;
                 const int trips = trips_of[r];                    // <= 16 (host check: a tile row holds <= 16 G atoms)
@@ -694,11 +741,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             const int totalN = __shfl(inclN, lane | (G - 1));
             unsigned short *epN = rowbuf + (unsigned)(inclN - mineN), *epF = rowbuf + (unsigned)(totalN + inclF - mineF);
             unsigned short *const ep_last = rowbuf + (ustride - 1u);
-            rv_next = rt[0];
+            rv_next = rt_get(rt, 0);
 #pragma unroll
             for (int r = 0; r < NROWS; r++) {
                 const int c0 = rv_next.x;
-                if (r + 1 < NROWS) rv_next = rt[r + 1];
+                if (r + 1 < NROWS) rv_next = rt_get(rt, r + 1);
                 // digit j (bit 2 j of the masks below) is tile slot c0 + gl + (trips - 1 - j) G
                 int base = (c0 + gl + (trips_of[r] - 1) * G) << a.idx_shift;
                 asm volatile("" : "+v"(base));
@@ -804,14 +851,14 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
             unsigned word[NWORDS];
             int cbase[NROWS];
-            const int2 *rt = rtab + (act ? oc : Shape::NOC) * 9;
+            const unsigned *rt = rtab + (act ? oc * NSUB + ((info.y >> 17) & 3) : Shape::NOC * NSUB) * 9;
             int2 rv_next = make_int2(0, 0);
             int trips_of[NROWS];
             if constexpr (RT) {
-                rv_next = rt[0];
+                rv_next = rt_get(rt, 0);
                 // chunk length of row gl (G = 8: rows 0..7 in the lanes, row 8 apart; G = 16: lanes 0..8 hold all nine)
-                int cv = (int)((unsigned)(rt[min(gl, NROWS - 1)].y + G - 1) / (unsigned)G);
-                int c8 = (int)((unsigned)(rt[NROWS - 1].y + G - 1) / (unsigned)G);
+                int cv = (int)((unsigned)(rt_get(rt, min(gl, NROWS - 1)).y + G - 1) / (unsigned)G);
+                int c8 = (int)((unsigned)(rt_get(rt, NROWS - 1).y + G - 1) / (unsigned)G);
                 if constexpr (G == 8) {
                     cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
                     c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
@@ -836,7 +883,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 int tcr = 0, c0, span;
                 if constexpr (RT) {
                     c0 = rv_next.x; span = rv_next.y;
-                    if (r + 1 < NROWS) rv_next = rt[r + 1];                        // one row ahead of its use
+                    if (r + 1 < NROWS) rv_next = rt_get(rt, r + 1);                        // one row ahead of its use
                 } else {
                     const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
                     tcr = ox + TX * ((oy + r % 3) + TY * (oz + r / 3));           // cell x-1 of tile row (dy, dz) = (r%3-1, r/3-1)

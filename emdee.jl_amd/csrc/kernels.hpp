@@ -106,6 +106,32 @@ struct RecPos {
     }
 };
 
+// ------------------------------------------------------------------------------------ x sub-bins (untyped boxes)
+// Inside a cell the atoms are ordered by the quarter of the cell (along x) they sit in: the sort digit is cell * S + sub-bin,
+// exactly as a typed box uses cell * 2 + species.  The tile rows of the neighbour build are runs of three cells along x, so
+// an atom in sub-bin s needs only the sub-bins >= s + K of the cell on its left and <= s - K of the cell on its right
+// (K = 0 when the cell is as wide as r_list): 9 of the 12 quarters of a row instead of all -- the build tests a quarter
+// fewer candidates (brick.hpp).  The sub-bin comes from the SAME product M t the cell does (voxel above), so an atom of
+// sub-bin s of cell v has M t in [v + s / S, v + (s + 1) / S) exactly.
+template <typename real, class Src>
+struct XSubBin {
+    Src src;
+    real lo, len;
+    int M, per, S;
+    __device__ __forceinline__ int of(int i) const {
+        real x, y, z;
+        src.get(i, x, y, z);
+        const real s = (x - lo) / len;
+        const real t = per ? s - floor(s) : s;
+        const real f = (real)M * t;
+        const int v = (int)floor(f);
+        if (v < 0) return 0;                       // (clamped into the first / last cell by voxel())
+        if (v > M - 1) return S - 1;
+        const int sb = (int)((f - (real)v) * (real)S);
+        return min(max(sb, 0), S - 1);
+    }
+};
+
 // ------------------------------------------------------------------------------------ species ("typed" boxes)
 // A box with 2 distinct LJAtom values is sorted by (cell, species): inside a cell the atoms of species 0 come first.
 // The LDS tiles of the brick kernels are then staged species-major, neighbour rows come out as one segment per neighbour

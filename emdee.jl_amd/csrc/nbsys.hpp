@@ -125,6 +125,11 @@ struct NbSystem {
     // cstart[] the per-cell ones every untyped consumer reads
     SpeciesTable species{1, {0, 0, 0, 0}};
     int nt = 1;
+    // untyped boxes on the brick path: a cell's atoms ordered by quarter along x (kernels.hpp XSubBin), digit = cell * nsub + quarter
+    int nsub = 1;
+    bool subbins_enabled = std::getenv("EMDEE_NO_SUBBINS") == nullptr && std::getenv("EMDEE_NO_BRICK_TABLES") == nullptr;
+    int digits() const { return nt > 1 ? nt : nsub; }
+    DevBuf<int> bsub;
     bool typed_enabled = std::getenv("EMDEE_NO_TYPED") == nullptr;
     DevBuf<int> cstart;
     DevBuf<unsigned long long> species_tab;
@@ -235,27 +240,43 @@ struct NbSystem {
     template <class Src, class Spc>
     void bin(Src src, const int *key, Spc spc) {
         const int n = n_total;
-        const size_t nbins = ncell * (size_t)nt;
+        const int dm = digits();
+        const size_t nbins = ncell * (size_t)dm;
         count.ensure(nbins + 2); fill.ensure(nbins + 2);
         EMDEE_HIP_CHECK(hipMemsetAsync(count.ptr, 0, (nbins + 1) * sizeof(int), stream()));
         EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, nbins * sizeof(int), stream()));
-        if (nt > 1) {
+        if (dm > 1) {
             cstart.ensure(ncell + 2);
             if (n == 0) EMDEE_HIP_CHECK(hipMemsetAsync(cstart.ptr, 0, (ncell + 1) * sizeof(int), stream()));
         }
         if (n == 0) return;
         hipLaunchKernelGGL((k_cell_assign<real, Src, Spc>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
-                           cell_of.ptr, count.ptr, spc, nt);
-        scanner.run(count.ptr, nbins + 1, stream());   // count[] becomes the start of every (cell, species) block
+                           cell_of.ptr, count.ptr, spc, dm);
+        scanner.run(count.ptr, nbins + 1, stream());   // count[] becomes the start of every (cell, species / sub-bin) block
         tmp2.ensure(n + 1);
         hipLaunchKernelGGL(k_cell_scatter_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            fill.ptr, key, tmp2.ptr);
         hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            tmp2.ptr, order.ptr);
-        if (nt > 1)
-            hipLaunchKernelGGL(k_cell_starts, dim3(blocks_for(ncell + 1, 256)), dim3(256), 0, stream(), (int)ncell, nt, count.ptr, cstart.ptr);
+        if (dm > 1)
+            hipLaunchKernelGGL(k_cell_starts, dim3(blocks_for(ncell + 1, 256)), dim3(256), 0, stream(), (int)ncell, dm, count.ptr, cstart.ptr);
     }
-    const int *start() const { return nt > 1 ? cstart.ptr : count.ptr; }   // first slot of every cell
+    // K: how many quarters of a neighbour cell lie beyond r_list whatever the atom's position in its own quarter: the
+    // quarters < s + K of the left cell are at least (1 + (K - 1) / 4) cell widths away.  0 for a cell a little wider than
+    // r_list; -1 (one more quarter on either side) when the cell is r_list to within 1e-4 -- the margin that covers the
+    // rounding of M t, fp32 positions included
+    int sub_k() const {
+        const double cx = len[0] / std::max(1, grid.M[0]);
+        return std::max(-1, (int)std::floor(4.0 * (1.0 - rlist * (1.0 + 1e-4) / cx)));
+    }
+    // sub-bins only where the round-robin two-phase build can use them: the tiled path of an untyped box
+    void choose_subbins() { nsub = (subbins_enabled && path == PATH_BRICK && nt == 1 && n_total > 0) ? 4 : 1; }
+    template <class Src>
+    void bin_untyped(Src src, const int *key) {
+        if (nsub > 1) bin(src, key, XSubBin<real, Src>{src, grid.lo[0], grid.len[0], grid.M[0], grid.per[0], nsub});
+        else bin(src, key, NoSpecies{});
+    }
+    const int *start() const { return digits() > 1 ? cstart.ptr : count.ptr; }   // first slot of every cell
     const int *tstart() const { return count.ptr; }                        // ... of every (cell, species) block (typed boxes)
 
     // caller-order arrays -> cell-ordered state (+ list)
@@ -271,13 +292,14 @@ struct NbSystem {
         detect_uniform_atoms(atoms);
         configure_grid();
         const int n = n_total;
+        choose_subbins();
         if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms});
-        else bin(UserPos<real>{pos}, nullptr, NoSpecies{});
+        else bin_untyped(UserPos<real>{pos}, nullptr);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img.ptr, nt);
+                               cell_sorted.ptr, img.ptr, digits());
         // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
         // from the start; their coordinates are refreshed by every halo unpack
         if (n > n_owned)
@@ -293,14 +315,15 @@ struct NbSystem {
         Timed t(this, T_REBUILD);
         const int n = n_total;
         configure_grid();
+        choose_subbins();
         if (nt > 1) bin(RecPos<real>{rec.ptr}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr});
-        else bin(RecPos<real>{rec.ptr}, perm.ptr, NoSpecies{});
+        else bin_untyped(RecPos<real>{rec.ptr}, perm.ptr);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
                                with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img2.ptr, nt);
+                               cell_sorted.ptr, img2.ptr, digits());
         rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2);
         if (with_vel) vel.swap(vel2);
         if (with_mass) im.swap(im2);
@@ -329,6 +352,8 @@ struct NbSystem {
         a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
         a.idx_shift = idx_shift;
         a.tstart = tstart();
+        a.nsub = nsub; a.fstart = tstart(); a.bsub = nsub > 1 ? bsub.ptr : nullptr;
+        a.sub_k = sub_k();
         for (int q = 0; q < 4; q++) { a.tsig2[q] = (real)0; a.te4[q] = (real)0; }
         if (nt == 2) {
             // sigma_ij^2 and 4 eps_ij of the four species pairs, with the operations the general-species pair loop uses
@@ -483,15 +508,15 @@ struct NbSystem {
                 // (a CU holds three workgroups only up to ~50,000 B each, not 160 KB / 3: measured in round 2 by padding the launch)
                 constexpr size_t USABLE = 150000;
                 auto per_cu = [&](int tc) {
-                    const size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB), f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
+                    const size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB, nsub), f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
                     return (int)(USABLE / std::max<size_t>(b, 1)) * 16 + (int)(USABLE / std::max<size_t>(f, 1));
                 };
                 while (tile_cap > exact && per_cu(tile_cap) < per_cu(exact)) tile_cap -= 16;
             }
             plan_span3 = max_span3 + max_span3 / 16 + 2;
             if (std::getenv("EMDEE_DEBUG_PLAN"))
-                std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d (max %d), own_cap %d (max %d), max 3-cell span %d\n", bgrid.nb[0],
-                             bgrid.nb[1], bgrid.nb[2], tile_cap, max_tile, own_cap, max_own, max_span3);
+                std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d (max %d), own_cap %d (max %d), max 3-cell span %d, x sub-bins %d K %d\n", bgrid.nb[0],
+                             bgrid.nb[1], bgrid.nb[2], tile_cap, max_tile, own_cap, max_own, max_span3, nsub, sub_k());
             build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && plan_span3 <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
             // crowded tile rows (long cutoffs): the same build with one 32-bit hit field per row
             if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && plan_span3 <= 32 * V::GB) build_alg = 5;
@@ -550,7 +575,7 @@ struct NbSystem {
         bool ok = true;
         with_brick_variant(variant, [&](auto v) {
             using V = decltype(v);
-            ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
+            ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, nsub) <= LDS_LIMIT;
             if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
         });
         return ok;
@@ -707,6 +732,7 @@ struct NbSystem {
                         BrickArgs<real> ta = brick_args();
                         ta.btab = btab.ptr;
                         ta.stats = (kept && maxima_from_tables) ? reinterpret_cast<unsigned long long *>(flags.ptr + 6) : nullptr;
+                        if (nsub > 1) { bsub.ensure((size_t)bgrid.nbricks * V::Shape::NTC + 4); ta.bsub = bsub.ptr; }
                         hipLaunchKernelGGL((k_brick_tables<real, typename V::Shape, TT>), dim3(bgrid.per_xcd * NXCD), dim3(TT),
                                            BT::bytes(0), stream(), ta);
                         btab_valid = true;
@@ -727,7 +753,7 @@ struct NbSystem {
                             if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
                         }
                     }
-                    lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
+                    lds_build_bytes = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, nsub);
                     allow_big_lds(kernel, lds_build_bytes);
                     hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(),
                                        brick_args());

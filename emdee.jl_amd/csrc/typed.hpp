@@ -449,8 +449,10 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
                 const int d = ti - c0;
                 if (d >= 0 && (d & (G - 1)) == gl) bits &= ~(1u << (d >> LOG2G));
             }
-            const int w = t * WPT + r / 2;
-            if (r & 1) word[w] |= bits << 16;
+            // rows (dy, dz) and (-dy, -dz) share a word: (0,8) (1,7) (2,6) (3,5) (4) -- their hits add up to nearly the same number
+            // for every atom, and the emission loop of a word runs as long as the busiest lane of the wavefront (brick.hpp)
+            const int w = t * WPT + (r <= 4 ? r : 8 - r);
+            if (r > 4) word[w] |= bits << 16;
             else word[w] = bits;
         }
         // ---- phase 2: per species, prefix over the lanes of the group, then every lane emits its hits ----------------
@@ -476,9 +478,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
 #pragma unroll
             for (int w = 0; w < WPT; w++) {
                 unsigned W = word[t * WPT + w];
-                // field A = row 2w of this species (bits 0..15), field B = row 2w+1 (bits 16..31)
-                int cA = (rt[t * NROWS + 2 * w].x + gl) << a.idx_shift;
-                int cB = (2 * w + 1 < NROWS) ? ((rt[t * NROWS + 2 * w + 1].x + gl - 16 * G) << a.idx_shift) : 0;
+                // field A = row w of this species (bits 0..15), field B = the opposite row 8 - w (bits 16..31)
+                int cA = (rt[t * NROWS + w].x + gl) << a.idx_shift;
+                int cB = (w < 4) ? ((rt[t * NROWS + 8 - w].x + gl - 16 * G) << a.idx_shift) : 0;
                 asm volatile("" : "+v"(cA), "+v"(cB));
                 while (W) {
                     const int k = __ffs((int)W) - 1;

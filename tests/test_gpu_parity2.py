@@ -65,6 +65,61 @@ def test_neighbour_set_is_the_oracles_set(emdee, oracle, dev, lj_sample, case):
         assert np.array_equal(got[i], want[i]), "row %d differs" % i
 
 
+@pytest.mark.parametrize("case", ["cell_equals_rlist", "wide_cells", "fp32_melt"])
+def test_neighbour_set_with_x_sub_bins(emdee, oracle, dev, case, monkeypatch, capfd):
+    """Untyped boxes are sorted by (cell, quarter of the cell along x) and the build skips the quarters of the left and right
+    cells that lie beyond r_list (kernels.hpp XSubBin, brick.hpp): the set must not change -- when the cell is exactly r_list
+    wide (K = -1: one quarter more on either side), when the cells are much wider than r_list (sparse box, K = 2), and in
+    fp32, where the fp32 distance test IS the definition of the set (against the same build without sub-bins)."""
+    E = emdee
+    rng = np.random.default_rng(11)
+    rc, rs, skin = 2.5, 2.0, 0.3
+    dtype, want_k = np.float64, None
+    if case == "cell_equals_rlist":
+        L, N, want_k = 8 * 2.8, 9000, -1
+        x = rng.uniform(0.0, L, size=(N, 3))
+    elif case == "wide_cells":
+        L, N, want_k = 40.0, 500, 2
+        x = rng.uniform(0.0, L, size=(N, 3))
+    else:
+        x, L = E.synthetic.fcc_positions(16)
+        x = x + rng.normal(0.0, 0.12, size=x.shape)
+        dtype, want_k = np.float32, 0
+    N = x.shape[0]
+    x = x.astype(dtype)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    lists = {}
+    for name, env in (("sub", {}), ("plain", {"EMDEE_NO_SUBBINS": "1"})):
+        monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tiles = E.nonbonded_computation_tiles(N, skin=skin)
+        f = torch.zeros((N, 3), dtype=tdt, device=dev)
+        E.compute_nonbonded_(f, None, None, E.cu(x, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(E.FORCES))
+        lists[name] = (_rows(*tiles.neighbor_lists()), f.cpu().numpy())
+        err = capfd.readouterr().err
+        for k in env:
+            monkeypatch.delenv(k)
+        plans = [l for l in err.splitlines() if l.startswith("emdee plan")]
+        assert plans, "the tiled path must be in use"
+        if name == "sub":
+            assert ("x sub-bins 4 K %d" % want_k) in plans[-1], plans[-1]
+        else:
+            assert "x sub-bins 1 " in plans[-1], plans[-1]
+    got, plain = lists["sub"][0], lists["plain"][0]
+    assert sum(len(r) for r in got) > 0
+    for i in range(N):
+        assert np.array_equal(got[i], plain[i]), "row %d differs from the build without sub-bins" % i
+    if dtype == np.float64:
+        want = _oracle_rows(oracle, x.astype(np.float64), L, rc + skin)
+        for i in range(N):
+            assert np.array_equal(got[i], want[i]), "row %d differs from the oracle" % i
+    # same set, other order inside a cell: the forces agree to rounding
+    fa, fb = lists["sub"][1], lists["plain"][1]
+    assert np.abs(fa - fb).max() <= (1e-10 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb).max())
+
+
 def test_neighbour_set_of_the_integrator_after_rebuilds(emdee, oracle, dev):
     """emdee_md_nbr_list after displacement-triggered rebuilds: the list is the oracle's list of the positions it was
     built from (read back at the same moment)."""
