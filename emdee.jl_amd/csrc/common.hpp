@@ -72,8 +72,7 @@ struct emdee_ctx {
     int32_t *host_flags = nullptr;   // pinned, device-visible: [0, 16) small blocking read-backs (copy + synchronize),
                                      // [POST_DATA, POST_DATA + POST_MAX) + stamp at POST_STAMP: read-backs posted by a kernel
     int32_t *post_dev = nullptr;     // the same memory as the device sees it
-    uint32_t post_seq = 0;
-    bool post_copy = false;          // EMDEE_READBACK=copy: every read-back as copy + synchronize (A/B)
+    uint32_t post_seq = 0;           // (EMDEE_READBACK=copy: every read-back as copy + synchronize, A/B)
 };
 
 namespace emdee {
@@ -128,8 +127,6 @@ static inline void host_words_alloc(emdee_ctx *ctx) {
     memset(ctx->host_flags, 0, HOST_WORDS * sizeof(int32_t));
     EMDEE_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->post_dev, ctx->host_flags, 0));
     ctx->post_seq = 0;
-    const char *e = std::getenv("EMDEE_READBACK");
-    ctx->post_copy = e != nullptr && std::string(e) == "copy";
 }
 
 static __global__ void k_post_words(const int *__restrict__ src, int n, volatile int *dst, volatile int *stamp, int seq) {
@@ -145,7 +142,9 @@ static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev
     EMDEE_REQUIRE(n >= 0 && n <= POST_MAX, EMDEE_ERR_INVALID, "read_back_words: %d words", n);
     if (n == 0) return;
     int32_t *data = ctx->host_flags + POST_DATA;
-    if (ctx->post_copy || ctx->post_dev == nullptr) {
+    // (EMDEE_READBACK is looked at per call, not per context: a process may hold one context for its whole life)
+    const char *form = std::getenv("EMDEE_READBACK");
+    if ((form != nullptr && form[0] == 'c') || ctx->post_dev == nullptr) {
         EMDEE_HIP_CHECK(hipMemcpyAsync(data, dev, n * sizeof(int), hipMemcpyDeviceToHost, s));
         EMDEE_HIP_CHECK(hipStreamSynchronize(s));
     } else {

@@ -120,6 +120,30 @@ def test_neighbour_set_with_x_sub_bins(emdee, oracle, dev, case, monkeypatch, ca
     assert np.abs(fa - fb).max() <= (1e-10 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb).max())
 
 
+def test_posted_read_backs_and_copies_give_the_same_run(emdee, dev, monkeypatch):
+    """The small blocking read-backs (rebuild requests of a batch of queued steps, the build's overflow words) are posted by a
+    kernel into pinned host memory while the host spins on a stamp; EMDEE_READBACK=copy takes hipMemcpyAsync +
+    hipStreamSynchronize instead.  Same decisions, same states, same number of rebuilds."""
+    E = emdee
+    x0, L = E.synthetic.fcc_positions(8)
+    N = x0.shape[0]
+    v0 = E.synthetic.velocities(N) * 1.4
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    out = {}
+    for name, env in (("posted", {}), ("copy", {"EMDEE_READBACK": "copy"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx_dev = torch.device("cuda", 0)
+        md = E.VelocityVerlet(E.cu(x0, ctx_dev), E.cu(v0, ctx_dev), L, E.LennardJonesModel(2.5, 2.0), E.cu(atoms, ctx_dev), skin=0.3)
+        md.step_(60, 0.005)
+        st = md.state()
+        out[name] = (st["positions"].cpu().numpy(), st["velocities"].cpu().numpy(), md.nbr_stats()["builds"])
+        for k in env:
+            monkeypatch.delenv(k)
+    assert np.array_equal(out["posted"][0], out["copy"][0]) and np.array_equal(out["posted"][1], out["copy"][1])
+    assert out["posted"][2] == out["copy"][2] >= 5
+
+
 def test_neighbour_set_of_the_integrator_after_rebuilds(emdee, oracle, dev):
     """emdee_md_nbr_list after displacement-triggered rebuilds: the list is the oracle's list of the positions it was
     built from (read back at the same moment)."""
