@@ -250,6 +250,7 @@ struct DdImpl : IDd {
     bool lockstep = true;                 // EMDEE_DD_LOCKSTEP=0: the overlapped form on three streams (round 2)
     bool halo_live = false;               // the halo stream holds work the compute stream has not waited for yet
     int mig_cap_forced = 0;               // EMDEE_DD_MIG_CAP=n: migrant rows per message (tests: 1 forces the redo with counts)
+    bool ghost_cap_exact = false;         // EMDEE_DD_GHOST_CAP=exact: ghost messages hold the rows of the previous rebuild and no more (tests)
     int64_t stat_fast = 0, stat_fallback = 0;
     int last_interval = 0;
     // Langevin
@@ -297,6 +298,7 @@ struct DdImpl : IDd {
         if (const char *e = std::getenv("EMDEE_DD_COUNT_FREE")) count_free = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_LOCKSTEP")) lockstep = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_MIG_CAP")) mig_cap_forced = std::max(1, std::atoi(e));
+        if (const char *e = std::getenv("EMDEE_DD_GHOST_CAP")) ghost_cap_exact = std::string(e) == "exact";
         for (int l = 0; l < n_local; l++) {
             dom.push_back(std::make_unique<Domain<real>>());   // registered first: release() sees whatever it gets below
             Domain<real> *d = dom.back().get();
@@ -727,7 +729,7 @@ struct DdImpl : IDd {
     }
 
     // capacity of a ghost message at the next rebuild, from its rows at this one (both ends hold the same number)
-    static int ghost_cap(int rows) { return rows + rows / 8 + 64; }
+    int ghost_cap(int rows) const { return ghost_cap_exact ? rows : rows + rows / 8 + 64; }
     void set_caps(Domain<real> &d) {
         const int np = d.geo.npeers;
         const int64_t per_rank = n_global > 0 ? n_global / world : (int64_t)d.n_owned;

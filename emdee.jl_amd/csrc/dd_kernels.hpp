@@ -360,13 +360,15 @@ __global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__
                                             const emdee_lj_atom *__restrict__ atoms, unsigned char *__restrict__ buf,
                                             int *__restrict__ codes, const int *__restrict__ w_over) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int over = w_over[DDW_OVER];
+    for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
     if (t < caps.npeers) {
-        int over = w_over[DDW_OVER];
-        for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
         int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(GhostRow<real>)) - DD_RHDR);
         hdr[0] = peer_count[t]; hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
     }
-    if (t >= caps.start[caps.npeers]) return;
+    // an overflow anywhere: the rebuild will be redone with counts and no row of this one is looked at -- and the send
+    // list (ids, bins, codes: sized by the capacities) does not hold what the counts say
+    if (over || t >= caps.start[caps.npeers]) return;
     const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
     if (slot >= peer_count[p]) return;
     int k = slot;

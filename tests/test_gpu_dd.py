@@ -131,7 +131,8 @@ def test_dd_count_free_rebuilds_give_the_same_trajectory(emdee, world, dtype, mo
     atoms = E.lennard_jones_atoms(eps, sigma)
     monkeypatch.setenv("EMDEE_DD_NO_SHORTCUT", "1")  # (a one-domain grid goes through the ownership path too)
     runs = {}
-    for name, env in (("counts", {"EMDEE_DD_COUNT_FREE": "0"}), ("free", {}), ("overflow", {"EMDEE_DD_MIG_CAP": "1"})):
+    for name, env in (("counts", {"EMDEE_DD_COUNT_FREE": "0"}), ("free", {}), ("overflow", {"EMDEE_DD_MIG_CAP": "1"}),
+                      ("ghost_overflow", {"EMDEE_DD_GHOST_CAP": "exact"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         dd = _build(E, world, pos, vel, atoms, L, dtype=tdt)
@@ -143,7 +144,7 @@ def test_dd_count_free_rebuilds_give_the_same_trajectory(emdee, world, dtype, mo
         dd.close()
     xc, vc, fc, sc, rc, ec = runs["counts"]
     assert rc["count_free"] == 0 and sc["rebuilds"] >= 6
-    for name in ("free", "overflow"):
+    for name in ("free", "overflow", "ghost_overflow"):
         x, v, f, st, rs, e = runs[name]
         assert np.array_equal(x, xc) and np.array_equal(v, vc) and np.array_equal(f, fc), name
         assert st["rebuilds"] == sc["rebuilds"] and st["migrated"] == sc["migrated"] and e == ec
@@ -153,6 +154,8 @@ def test_dd_count_free_rebuilds_give_the_same_trajectory(emdee, world, dtype, mo
     if world > 1:
         assert sc["migrated"] > N // 4               # (the scattered initial slices, then the hot box)
         assert runs["overflow"][4]["redone"] > 0 and runs["overflow"][4]["migrant_rows_per_peer"] == 1
+        # ghost messages without headroom: a peer's ghost count grows at some rebuild, its message overflows, everybody redoes
+        assert runs["ghost_overflow"][4]["redone"] > 0
 
 
 @pytest.mark.parametrize("world,ncell", [(8, 12), (3, 10), (2, 8)])
