@@ -850,7 +850,12 @@ struct DdImpl : IDd {
             EMDEE_REQUIRE(d.host_w[DDW_ERR] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom of domain %d left the neighbourhood of its brick", d.geo.rank);
             over = over || d.host_w[DDW_OVER] != 0;
         }
-        if (over) return false;                                // (the same word on every rank: see k_dd_ghost_counts)
+        // the same word on every rank (k_dd_ghost_counts): ranks in separate processes have nothing but that to agree on the
+        // redo, so the validation mode -- all domains here -- insists on it
+        for (auto &pd : dom)
+            EMDEE_REQUIRE((pd->host_w[DDW_OVER] != 0) == over, EMDEE_ERR_STATE,
+                          "emdee_dd: the domains disagree on whether a rebuild message overflowed (domain %d)", pd->geo.rank);
+        if (over) return false;
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
             const int np = d.geo.npeers;

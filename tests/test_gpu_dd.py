@@ -60,7 +60,8 @@ def _gather(dd, world, N):
 
 
 @pytest.mark.parametrize("world,rebuild_every,langevin,uniform",
-                         [(2, 0, 0, 0), (4, 0, 0, 0), (8, 0, 0, 1), (3, 0, 0, 0), (2, 4, 0, 0), (4, 7, 1, 1), (8, 0, 1, 0), (1, 0, 0, 0)])
+                         [(2, 0, 0, 0), (4, 0, 0, 0), (8, 0, 0, 1), (3, 0, 0, 0), (2, 4, 0, 0), (4, 7, 1, 1), (8, 0, 1, 0), (1, 0, 0, 0),
+                          (1, 0, 1, 1), (1, 5, 1, 0)])   # (one domain = the lock-step halves of a production rank; with the thermostat's noise)
 def test_dd_trajectory_matches_oracle(emdee, oracle, world, rebuild_every, langevin, uniform):
     E = emdee
     pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform)
