@@ -263,11 +263,13 @@ struct NbSystem {
     }
     // K: how many quarters of a neighbour cell lie beyond r_list whatever the atom's position in its own quarter: the
     // quarters < s + K of the left cell are at least (1 + (K - 1) / 4) cell widths away.  0 for a cell a little wider than
-    // r_list; -1 (one more quarter on either side) when the cell is r_list to within 1e-4 -- the margin that covers the
-    // rounding of M t, fp32 positions included
+    // r_list; -1 (one more quarter on either side) when the cell is r_list to within the margin that covers the rounding
+    // of M t in the box's own precision (t carries ~2 ulp of 1, M t as many ulp of M: 16 M eps is 8e-5 for the fp32 10^7-atom
+    // box, whose cells are 8.6e-4 wider than r_list)
     int sub_k() const {
         const double cx = len[0] / std::max(1, grid.M[0]);
-        return std::max(-1, (int)std::floor(4.0 * (1.0 - rlist * (1.0 + 1e-4) / cx)));
+        const double margin = 16.0 * grid.M[0] * (sizeof(real) == 4 ? 6.0e-8 : 1.2e-16) + 1e-9;
+        return std::max(-1, (int)std::floor(4.0 * (1.0 - rlist * (1.0 + margin) / cx)));
     }
     // sub-bins only where the round-robin two-phase build can use them: the tiled path of an untyped box
     void choose_subbins() { nsub = (subbins_enabled && path == PATH_BRICK && nt == 1 && n_total > 0) ? 4 : 1; }
