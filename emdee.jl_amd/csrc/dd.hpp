@@ -399,34 +399,41 @@ struct DdImpl : IDd {
             return;
         }
         if (inl) return;                                       // one domain without peers: nobody to copy from
-        // all domains in this process: the receiver's communication stream copies from the sender's buffer
+        // all domains in this process: ONE communication stream (the first domain's) waits for every domain's send buffer,
+        // then every receiver pulls its messages with one launch (k_dd_pull); every domain's ev_done marks the end of ALL
+        // pulls, so a domain that has waited for its own may unpack AND pack again (nobody still reads its send buffer)
+        hipStream_t cs = dom[0]->comm;
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamWaitEvent(cs, pd->ev_packed, 0));
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, d.ev_packed, 0));   // (my receive buffer has been consumed)
+            PullArgs pa{};
+            unsigned most = 0;
             for (int p = 0; p < d.geo.npeers; p++) {
                 Domain<real> &s = *dom[d.geo.peers[p] - rank_first];
                 const int q = s.geo.peer_index(d.geo.rank);
                 EMDEE_REQUIRE(q >= 0 && s.xf.sbytes[q] == d.xf.rbytes[p], EMDEE_ERR_STATE,
                               "emdee_dd: message sizes of domains %d and %d disagree (%zu sent, %zu expected)", s.geo.rank,
                               d.geo.rank, q >= 0 ? s.xf.sbytes[q] : (size_t)0, d.xf.rbytes[p]);
-                EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, s.ev_packed, 0));
-                if (d.xf.rbytes[p])
-                    EMDEE_HIP_CHECK(hipMemcpyAsync(d.xf.recv + d.xf.roff[p], s.xf.send + s.xf.soff[q], d.xf.rbytes[p],
-                                                   hipMemcpyDeviceToDevice, d.comm));
+                if (d.xf.rbytes[p] == 0) continue;
+                EMDEE_REQUIRE(d.xf.rbytes[p] % 4 == 0 && d.xf.roff[p] % 4 == 0 && s.xf.soff[q] % 4 == 0, EMDEE_ERR_STATE,
+                              "emdee_dd: a message that is not a whole number of words");
+                PullSeg &g = pa.seg[pa.n++];
+                g.src = reinterpret_cast<const unsigned *>(s.xf.send + s.xf.soff[q]);
+                g.dst = reinterpret_cast<unsigned *>(d.xf.recv + d.xf.roff[p]);
+                g.words = (unsigned)(d.xf.rbytes[p] / 4);
+                most = std::max(most, g.words);
             }
+            if (pa.n > 0)
+                hipLaunchKernelGGL(k_dd_pull, dim3(std::min(64u, blocks_for(most, 1024)), pa.n), dim3(256), 0, cs, pa);
         }
-        for (auto &pd : dom) EMDEE_HIP_CHECK(hipEventRecord(pd->ev_done, pd->comm));
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipEventRecord(pd->ev_done, cs));
     }
     // compute streams wait for the arrival of their messages -- and, with in-process copies, for everybody
     // who reads this domain's send buffer, before it is packed again
     void wait_exchange() {
         if (inline_exchange()) return;
-        for (auto &pd : dom) {
-            EMDEE_HIP_CHECK(hipStreamWaitEvent(pd->stream(), pd->ev_done, 0));
-            if (!use_rccl)
-                for (int p = 0; p < pd->geo.npeers; p++)
-                    EMDEE_HIP_CHECK(hipStreamWaitEvent(pd->stream(), dom[pd->geo.peers[p] - rank_first]->ev_done, 0));
-        }
+        // (in-process copies: a domain's ev_done lies behind the pulls of ALL domains, those that read its send buffer included)
+        for (auto &pd : dom) EMDEE_HIP_CHECK(hipStreamWaitEvent(pd->stream(), pd->ev_done, 0));
     }
     // sum of n doubles over all domains (vals: per local domain n values on the host; result in out)
     void allreduce_sum(const std::vector<std::vector<double>> &vals, int n, double *out) {

@@ -418,6 +418,25 @@ __global__ void k_dd_unpack_ghost_rows_padded(int n, DdPlan plan, DdCaps rcaps, 
     atoms[k] = a;
 }
 
+// ------------------------------------------------------------------------------------ in-process transport
+// Validation mode (all domains of the grid in one process on one device): a receiving domain pulls the messages of all
+// its peers with ONE launch -- segment blockIdx.y of `a`, 4-byte words (message offsets and sizes are multiples of 4) --
+// where round 2 queued one device copy per message: 56 copies per step of an 8-domain grid, and the one host thread that
+// drives all eight domains was what the rehearsal measured.
+struct PullSeg {
+    const unsigned *src;
+    unsigned *dst;
+    unsigned words;
+};
+struct PullArgs {
+    int n;
+    PullSeg seg[DD_MAX_PEERS];
+};
+static __global__ void k_dd_pull(PullArgs a) {
+    const PullSeg s = a.seg[blockIdx.y];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < s.words; i += gridDim.x * blockDim.x) s.dst[i] = s.src[i];
+}
+
 // ------------------------------------------------------------------------------------ per-step halo messages
 // Message to peer p: [int request | pad to DD_HDR][3 reals per atom].  The request word is this domain's
 // "one of my atoms has moved skin/2" flag for the positions being sent: it rides on the halo message, so the
