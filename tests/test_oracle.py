@@ -69,6 +69,45 @@ def test_interaction_survey_values(oracle):
         assert E == pytest.approx(E0, rel=1e-10) and W == pytest.approx(W0, rel=1e-10)
 
 
+def test_interaction_is_a_potential_and_its_virial(oracle):
+    """A property of the reference's pair function that no restatement of its lines can satisfy by accident: the second
+    value returned by interaction() (src/lennard_jones.jl:25-42: W g + E (-r g')) is the virial -r dE/dr of the first
+    (E g, the switched Lennard-Jones energy), on both sides of rs and right up to rc, for like and unlike atoms; and
+    the naive double loop's force on an atom is minus the gradient of the total energy it reports
+    (src/nonbonded.jl:136-145).  Checked by Richardson-extrapolated central differences of the oracle's own energies."""
+    def dE_dr(m, ai, aj, r, h=1e-4):
+        E = lambda q: oracle.interaction(q * q, m, ai, aj, oracle.LITERAL)[0]
+        d1 = (E(r + h) - E(r - h)) / (2 * h)
+        d2 = (E(r + 2 * h) - E(r - 2 * h)) / (4 * h)
+        return (4 * d1 - d2) / 3                     # O(h^4)
+    for rc, rs in ((3.0, 2.5), (2.5, 2.0), (3.5, 3.0)):
+        m = oracle.model(rc, rs)
+        for ai, aj in (((0.5, 2.0), (0.5, 2.0)), ((0.45, 2.2), (0.6, 1.7)), ((0.5, 2.0), (0.55, 0.0))):
+            for r in np.concatenate([np.linspace(0.92, rs - 0.01, 7), np.linspace(rs + 0.01, rc - 0.01, 9)]):
+                E, W = oracle.interaction(r * r, m, ai, aj, oracle.LITERAL)
+                want = -r * dE_dr(m, ai, aj, r)
+                assert W == pytest.approx(want, rel=2e-7, abs=2e-9), (rc, rs, ai, aj, r)
+    # forces of the double loop = -grad of its total energy (a few atoms of a small random box, one coordinate each)
+    rng = np.random.default_rng(3)
+    N, L = 40, 8.0
+    x = rng.uniform(0, L, size=(N, 3))
+    eps, sig = rng.uniform(0.6, 1.4, N), rng.uniform(0.85, 1.1, N)
+    atoms = oracle.lj_atoms(eps, sig)
+    m = oracle.model(3.0, 2.5)
+    f, e, w = oracle.naive(x, L, m, atoms, oracle.CUTOFF)
+    tot = lambda y: oracle.naive(y, L, m, atoms, oracle.CUTOFF)[1].sum()
+    h = 1e-5
+    for i, d in ((0, 0), (7, 1), (23, 2), (39, 0)):
+        xp, xm = x.copy(), x.copy()
+        xp[i, d] += h; xm[i, d] -= h
+        assert f[i, d] == pytest.approx(-(tot(xp) - tot(xm)) / (2 * h), rel=1e-6, abs=1e-7)
+    # and the per-atom virials add up to sum over pairs of r . f = -sum_i x_i . f_i only up to the images: check the pair form
+    assert w.sum() == pytest.approx(sum(0.5 * oracle.interaction(float(np.sum((dx - L * np.rint(dx / L)) ** 2)), m,
+                                        (atoms["half_sigma"][i], atoms["twice_sqrt_eps"][i]), (atoms["half_sigma"][j], atoms["twice_sqrt_eps"][j]),
+                                        oracle.CUTOFF)[1] for i in range(N) for j in range(N) if i != j
+                                        for dx in [x[i] - x[j]]), rel=1e-12)
+
+
 def test_interaction_f32_follows_reference_precision(oracle):
     """Float32 instantiation (the reference's precision) agrees with the exact values to fp32 rounding."""
     for row in _kat_rows():
