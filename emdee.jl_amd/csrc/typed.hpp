@@ -124,6 +124,18 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
         T.gbeg[tid] = gb;
         if (t == 0) T.shift[tc] = sh;
     }
+    // Decomposed runs: an own (species, cell) block that holds nothing but ghosts takes no part in the own-atom loops (as in
+    // brick.hpp): bit 8 + species of the cell's shift word, set once the plain words are in place
+    int ghosts_only = 0;
+    if (COMPUTE && a.n_owned < a.n && tid < NTT && my_cnt > 0) {
+        const int tc = tid % NTC, tx = tc % TX, ty = (tc / TX) % TY, tz = tc / (TX * TY);
+        if (tx >= 1 && tx <= BX && ty >= 1 && ty <= BY && tz >= 1 && tz <= BZ) {
+            int owned = 0;
+            const int gb = T.gbeg[tid];
+            for (int k = 0; k < my_cnt; k++) owned |= (a.perm[gb + k] < a.n_owned) ? 1 : 0;
+            ghosts_only = owned ? 0 : 1;
+        }
+    }
     {   // exclusive scan of my_cnt over the first NTT threads; tile slots start at 1 (slot 0 is the sentinel record)
         int inc = my_cnt;
 #pragma unroll
@@ -137,6 +149,7 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
         for (int w = 0; w < wv; w++) woff += T.wtot[w];
         if (tid < NTT) T.off[tid] = 1 + woff + inc - my_cnt;
         if (tid == NTT - 1) T.off[NTT] = 1 + woff + inc;
+        if (ghosts_only) atomicOr(&T.shift[tid % NTC], 256 << (tid / NTC));   // (the shift words were stored before the barrier above)
     }
     __syncthreads();
     tile_n = T.off[NTT];
@@ -147,7 +160,8 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const int tc = t * NTC + (ox + 1) + TX * ((oy + 1) + TY * (oz + 1));
             T.own[q] = acc;
-            const bool mine = (bxi * BX + ox < Mx) && (byi * BY + oy < My) && (bzi * BZ + oz < Mz);
+            const bool mine = (bxi * BX + ox < Mx) && (byi * BY + oy < My) && (bzi * BZ + oz < Mz) &&
+                              !(T.shift[tc - t * NTC] & (256 << t));
             acc += mine ? (T.off[tc + 1] - T.off[tc]) : 0;
         }
         T.own[NOT] = acc;
