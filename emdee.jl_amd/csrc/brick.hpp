@@ -40,6 +40,13 @@ namespace emdee {
 // no separate kick/drift pass and no force array round trip.
 enum BrickMode { BRICK_FORCE = 1, BRICK_STATS = 2, BRICK_STEP = 3 };
 
+// a loop the compiler must leave as written (no unrolling, no interleaving of trips behind run-time alias checks)
+#ifndef EMDEE_NO_PLAIN_LOOPS
+#define EMDEE_PLAIN_LOOP _Pragma("clang loop unroll(disable) vectorize(disable) interleave(disable)")
+#else
+#define EMDEE_PLAIN_LOOP
+#endif
+
 constexpr int EPL = 8;   // neighbour entries per lane per 16-byte load
 // entries the force kernels read of every row without looking at its length: the NPF prefetched blocks of 8 G entries
 // and the one after them (rows are sentinel-padded, so the row stride must hold them)
@@ -777,6 +784,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             }
             if (have) {
                 constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
+                // (left to itself the compiler interleaves two trips of this loop behind a run-time alias check and splits each
+                // 16-byte store into four: 130 instructions per atom where 40 do -- the flush was 0.32 ms of the build for that)
+                EMDEE_PLAIN_LOOP
                 for (int c = gl * EPL; c < a.stride; c += G * EPL) {
                     const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7
                     uint4 q;
@@ -1058,6 +1068,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             if (have) {
 #endif
                 constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
+                EMDEE_PLAIN_LOOP
                 for (int c = gl * EPL; c < a.stride; c += G * EPL) {
                     const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7
                     uint4 q;
