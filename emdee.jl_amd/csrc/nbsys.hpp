@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "brick.hpp"
+#include "brick_tbuild.hpp"
 #include "kernels.hpp"
 #include "typed.hpp"
 
@@ -113,6 +114,16 @@ struct NbSystem {
     int build_alg = 1;                    // k_brick_build ALG (2 = two-phase; 1 when a tile row is too crowded for it)
     bool force_build1 = false;            // EMDEE_BUILD_ALG=1: A/B switch
     int build_alg_pref = 3;               // EMDEE_BUILD_ALG=2: the two-phase build with the per-lane candidate loop
+    // the transposed build (brick_tbuild.hpp: candidates in the lanes, own atoms in the loop) for the default variant of untyped
+    // boxes.  Measured in round 4 and left OFF (EMDEE_TBUILD=1 switches it on): same neighbour set, 2.63 ms per build at 10^7
+    // atoms against k_brick_build's 1.90 (profiles/r04/tbuild_*.txt).  tbuild_blocked: a cell of this state has more candidates
+    // than the kernel's registers hold (it raised flags[3]) -- until the next load
+    bool tbuild_enabled = std::getenv("EMDEE_TBUILD") != nullptr && std::atoi(std::getenv("EMDEE_TBUILD")) != 0 &&
+                          std::getenv("EMDEE_BUILD_ALG") == nullptr && std::getenv("EMDEE_BUILD_NEARFAR") == nullptr;
+    bool tbuild_blocked = false;
+    static constexpr int TB_NPAIR = 5;    // 640 candidates per own cell (27 cells of 17.6 atoms at rho* = 0.8, r_list = 2.8: 475)
+    template <class V>
+    bool tbuild_active() const { return tbuild_enabled && !tbuild_blocked && !typed_active && std::is_same<V, BrickVariant<0>>::value; }
     size_t lds_bytes = 0, lds_build_bytes = 0;
     float build_margin = 0.f;
 
@@ -510,7 +521,9 @@ struct NbSystem {
                 // (a CU holds three workgroups only up to ~50,000 B each, not 160 KB / 3: measured in round 2 by padding the launch)
                 constexpr size_t USABLE = 150000;
                 auto per_cu = [&](int tc) {
-                    const size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB, nsub), f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
+                    const size_t b = tbuild_active<V>() ? brick_tbuild_lds_bytes<S, V::THREADS, TB_NPAIR>(tc, own_cap, st)
+                                                        : brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB, nsub),
+                                 f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
                     return (int)(USABLE / std::max<size_t>(b, 1)) * 16 + (int)(USABLE / std::max<size_t>(f, 1));
                 };
                 while (tile_cap > exact && per_cu(tile_cap) < per_cu(exact)) tile_cap -= 16;
@@ -524,6 +537,7 @@ struct NbSystem {
             if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && plan_span3 <= 32 * V::GB) build_alg = 5;
             if (build_alg == 1) plan_span3 = 1 << 30;               // the ballot build has no limit
             else plan_span3 = (build_alg == 5 ? 32 : BUILD2_FIELD) * V::GB;   // what the chosen build can take
+            if (tbuild_active<V>()) plan_span3 = 1 << 30;           // the transposed build reports a crowded cell itself (flags[3])
             lds_bytes = brick_force_lds_bytes<real, S, V::THREADS>(tile_cap, own_cap);
             ok = lds_bytes <= LDS_LIMIT && tile_cap < 65536;
             // fp32 pre-test of the build kernel (fp64 boxes): brick-relative coordinates are below
@@ -578,6 +592,7 @@ struct NbSystem {
         with_brick_variant(variant, [&](auto v) {
             using V = decltype(v);
             ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, nsub) <= LDS_LIMIT;
+            if (tbuild_active<V>()) ok = brick_tbuild_lds_bytes<typename V::Shape, V::THREADS, TB_NPAIR>(tile_cap, own_cap, stride) <= LDS_LIMIT;
             if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
         });
         return ok;
@@ -700,7 +715,7 @@ struct NbSystem {
         }
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 3 * sizeof(int), stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(int), stream()));
             if (brick_active) {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
@@ -739,6 +754,15 @@ struct NbSystem {
                                            BT::bytes(0), stream(), ta);
                         btab_valid = true;
                     }
+                    if constexpr (std::is_same<V, BrickVariant<0>>::value) {
+                        if (tbuild_active<V>()) {
+                            auto tk = k_brick_build_t<real, typename V::Shape, V::THREADS, V::G, TB_NPAIR>;
+                            lds_build_bytes = brick_tbuild_lds_bytes<typename V::Shape, V::THREADS, TB_NPAIR>(tile_cap, own_cap, stride);
+                            allow_big_lds(tk, lds_build_bytes);
+                            hipLaunchKernelGGL(tk, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(), brick_args());
+                            return;
+                        }
+                    }
                     auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 1, V::G>;
                     if constexpr (V::GB == 8 || V::GB == 16) {
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
@@ -772,6 +796,15 @@ struct NbSystem {
             read_back_words(ctx, stream(), flags.ptr, 9, ctx->host_flags);
             if (kept && (!plan_holds(ctx->host_flags + 6) || ctx->host_flags[2] != 0)) {
                 // the populations outgrew the kept plan (the kernels skipped the bricks concerned): plan afresh and build again
+                kept = false;
+                plan_valid = false;
+                btab_valid = false;
+                make_plan();
+                continue;
+            }
+            if (brick_active && ctx->host_flags[3] != 0 && !tbuild_blocked) {
+                // a cell with more candidates than the transposed build holds in registers: this state goes on with k_brick_build
+                tbuild_blocked = true;
                 kept = false;
                 plan_valid = false;
                 btab_valid = false;
@@ -832,6 +865,7 @@ struct NbSystem {
         nt = 1;
         species.n = 1;
         typed_blocked = false;
+        tbuild_blocked = false;
         if (uniform_known >= 0 && n_total > 0) {
             uniform_atoms = uniform_known == 1;
             // (decomposed runs: the two species every domain agreed on at the first load, emdee_dd_load)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, GPU call C: kernel trace of the transposed build
+O=$PWD/gpurun_out/r04c; mkdir -p $O; R=$PWD
+cd /tmp && export TMPDIR=/tmp
+export EMDEE_RUN_AHEAD=1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1 || echo "stats failed"
+cd $R; F=$(find $O/stats -name "*kernel_stats.csv" | head -1); python3 - "$F" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:14]:
+    print("%-90s calls %5s avg %10.1f us total %8.2f ms" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY

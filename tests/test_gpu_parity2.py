@@ -120,6 +120,47 @@ def test_neighbour_set_with_x_sub_bins(emdee, oracle, dev, case, monkeypatch, ca
     assert np.abs(fa - fb).max() <= (1e-10 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb).max())
 
 
+@pytest.mark.parametrize("case", ["fcc_jitter_f64", "random_gas_f64", "fcc_jitter_f32"])
+def test_neighbour_set_of_the_transposed_build(emdee, oracle, dev, case, monkeypatch):
+    """EMDEE_TBUILD=1: k_brick_build_t (brick_tbuild.hpp: the candidates of an own cell in the lanes' registers, its atoms in
+    the loop, hits stored at base + v_mbcnt) -- measured in round 4 and left off (profiles/r04/tbuild_transposed_build.txt), but
+    it is in the library: same neighbour SET as the default build and, in fp64, as the oracle; same forces to rounding."""
+    E = emdee
+    rng = np.random.default_rng(23)
+    rc, rs, skin = 2.5, 2.0, 0.3
+    dtype = np.float32 if case.endswith("f32") else np.float64
+    if case.startswith("fcc"):
+        x, L = E.synthetic.fcc_positions(14)
+        x = x + rng.normal(0.0, 0.1, size=x.shape)
+    else:
+        L, N = 9 * 2.8, 14000
+        x = rng.uniform(0.0, L, size=(N, 3))
+    x = x.astype(dtype)
+    N = x.shape[0]
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    out = {}
+    for name in ("default", "transposed"):
+        if name == "transposed":
+            monkeypatch.setenv("EMDEE_TBUILD", "1")
+        tiles = E.nonbonded_computation_tiles(N, skin=skin)
+        f = torch.zeros((N, 3), dtype=tdt, device=dev)
+        E.compute_nonbonded_(f, None, None, E.cu(x, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(E.FORCES))
+        out[name] = (_rows(*tiles.neighbor_lists()), f.cpu().numpy())
+    monkeypatch.delenv("EMDEE_TBUILD")
+    got, ref = out["transposed"][0], out["default"][0]
+    assert sum(len(r) for r in got) > 10 * N
+    for i in range(N):
+        assert np.array_equal(got[i], ref[i]), "row %d differs from the default build" % i
+    if dtype == np.float64:
+        want = _oracle_rows(oracle, x, L, rc + skin)
+        for i in range(N):
+            assert np.array_equal(got[i], want[i]), "row %d differs from the oracle" % i
+    fa, fb = out["transposed"][1], out["default"][1]
+    finite = np.isfinite(fb).all(axis=1)                              # (a random gas has pairs at r -> 0)
+    assert np.abs(fa[finite] - fb[finite]).max() <= (1e-9 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb[finite]).max())
+
+
 def test_posted_read_backs_and_copies_give_the_same_run(emdee, dev, monkeypatch):
     """The small blocking read-backs (rebuild requests of a batch of queued steps, the build's overflow words) are posted by a
     kernel into pinned host memory while the host spins on a stamp; EMDEE_READBACK=copy takes hipMemcpyAsync +
