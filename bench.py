@@ -33,6 +33,7 @@ cores on a bounded sample of the same box.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -244,6 +245,48 @@ def make_box(pkg, cells, mixture):
     else:
         atoms = pkg.lennard_jones_atoms(1.0, 1.0, N)
     return pos, vel, atoms, L
+
+
+def load_traffic_entries(path=None):
+    """profiles/traffic.json: PMC-measured HBM bytes per launch of the step kernel, one entry per measured configuration
+    (profiles/pmc_traffic.sh, profiles/collect.sh).  [] if the file is missing or unreadable."""
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            data = json.load(fh)
+    except (OSError, ValueError):
+        return []
+    if isinstance(data, dict) and "entries" in data:
+        return list(data["entries"])
+    return [dict(data, rc=2.5, mixture=False)] if isinstance(data, dict) else []
+
+
+def traffic_floor(atoms, word_bytes, rc, density=0.8):
+    """Bytes a fused step launch cannot do without: the 21 words per atom of SURVEY.md 8(d) and ONE 2-byte list entry per
+    in-cutoff neighbour.  (The algorithmic figure of 8(d) counts 4 bytes per neighbour; this library's entries are uint16
+    tile slots, so a measured launch may come in slightly under it -- fp32 at 10^7 atoms: 291 against 293 B/atom -- but never
+    under this.)"""
+    nbar = (4.0 / 3.0) * math.pi * rc ** 3 * density
+    return atoms * (21.0 * word_bytes + 2.0 * nbar)
+
+
+def pick_traffic(entries, atoms, dtype, rc, mixture, floor_bytes):
+    """The entry measured on EXACTLY this configuration -- atoms per GPU, arithmetic type, cutoff, one or two species -- or
+    None: a line never carries another configuration's traffic (round 3 attached the single-species figure to the mixture
+    line: 4.19 GB of traffic against 7.44 GB of algorithmic bytes).  An entry below the bytes the launch cannot do without
+    (traffic_floor) cannot be a measurement of this kernel and is refused as well."""
+    for e in entries:
+        try:
+            same = (int(e["atoms"]) == int(atoms) and e["dtype"] == dtype and abs(float(e.get("rc", 2.5)) - float(rc)) < 1e-9
+                    and bool(e.get("mixture", False)) == bool(mixture))
+        except (KeyError, TypeError, ValueError):
+            continue
+        if same:
+            b = e.get("lj_force_nbr_bytes_per_launch")
+            if b is None or (floor_bytes is not None and b < floor_bytes):
+                return None
+            return e
+    return None
 
 
 def cpu_baseline(pkg, args):
@@ -533,7 +576,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "LJ fcc box rho*=0.8 rc=%gsigma rs=%gsigma%s, %d atoms (%s), velocity-Verlet dt=%g, skin %g"
                                % (rc, rs, " binary mixture" if args.mixture else "", N_total, shape, args.dt, args.skin),
-                   "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "parallelism": parallelism,
+                   "atoms": N_total, "atoms_per_gpu": N_total / world, "atoms_rank0": N_rank, "rc": rc, "mixture": bool(args.mixture),
+                   "parallelism": parallelism,
                    "decomposition": dd_engine, "decomposition_probe": dd_probe, "halo_exchange": halo_mode,
                    "rebuild": "every %d steps" % args.rebuild_every if args.rebuild_every else "max displacement > skin/2",
                    "thermostat": "langevin gamma=%g T*=1" % args.langevin if args.langevin > 0.0 else "none (NVE)"},
@@ -576,16 +620,11 @@ def main():
                     out["one_gpu_reference"] = one
             except (OSError, ValueError):
                 pass
-        traffic = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic):
-            try:
-                with open(traffic) as fh:
-                    t = json.load(fh)
-                if t.get("atoms") == N_rank and t.get("dtype") == out["dtype"]:
-                    out["roofline"]["traffic"] = t.get("lj_force_nbr_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = t.get("source")
-            except Exception:
-                pass
+        t = pick_traffic(load_traffic_entries(), N_rank, out["dtype"], args.rc, bool(args.mixture),
+                         traffic_floor(N_rank, 8 if out["dtype"] == "f64" else 4, args.rc))
+        if t is not None:
+            out["roofline"]["traffic"] = t.get("lj_force_nbr_bytes_per_launch")
+            out["roofline"]["traffic_source"] = t.get("source")
         # the same kernel against the limit that actually binds it in fp64 ("report VALU
         # utilisation next to GB/s"): instruction counts from the committed SQ counter pass, live duration
         valu = os.path.join(ROOT, "profiles", "valu.json")

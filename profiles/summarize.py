@@ -58,7 +58,15 @@ if f_kb is not None and w_kb is not None:
         atoms=N, dtype=bench["dtype"], kernel="k_brick<..., BRICK_STEP, 1> (lj_force_nbr with the fused velocity-Verlet update)",
         fetch_size_kb_per_launch=f_kb, write_size_kb_per_launch=w_kb,
         lj_force_nbr_bytes_per_launch=int((2 * f_kb + w_kb) * 1024), bytes_per_atom=(2 * f_kb + w_kb) * 1024 / N)
-    json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+    traffic.update(rc=float(bench["config"].get("rc", 2.5)), mixture=bool(bench["config"].get("mixture", False)))
+    tpath = os.path.join(root, "traffic.json")
+    data = {"entries": []}
+    if os.path.exists(tpath):
+        old = json.load(open(tpath))
+        data = old if "entries" in old else {"entries": [dict(old, rc=2.5, mixture=False)]}
+    key = lambda e: (int(e["atoms"]), e["dtype"], float(e.get("rc", 2.5)), bool(e.get("mixture", False)))
+    data["entries"] = sorted([e for e in data["entries"] if key(e) != key(traffic)] + [traffic], key=key)
+    json.dump(data, open(tpath, "w"), indent=1)
     print("traffic: %.1f B/atom per launch" % traffic["bytes_per_atom"])
 
 # ---- SQ instruction counters of the fused kernel: how close the kernel is to the VALU issue limit ----------

@@ -179,3 +179,36 @@ def test_probe_agrees_on_failure_without_a_gpu(tmp_path):
     assert [r["ok"] for r in res] == [False, False]
     assert all(r["seconds"] < 80.0 for r in res)
     assert any("probe" in r["note"] for r in res)
+
+
+def test_a_line_only_carries_traffic_measured_on_its_own_configuration():
+    """profiles/traffic.json is keyed by (atoms per GPU, dtype, rc, one or two species) and bench.py
+    attaches an entry on an exact match only; an entry below the line's algorithmic bytes is refused.  Checked on the
+    committed file for every BASELINE configuration bench.py can be asked for."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    entries = bench.load_traffic_entries()
+    assert entries, "profiles/traffic.json holds the headline configuration at least"
+    keys = [(int(e["atoms"]), e["dtype"], float(e.get("rc", 2.5)), bool(e.get("mixture", False))) for e in entries]
+    assert len(set(keys)) == len(keys)
+    N = 10061824
+    nbar = lambda rc: (4.0 / 3.0) * 3.141592653589793 * rc ** 3 * 0.8
+    alg = lambda w, rc: bench.traffic_floor(N, w, rc)            # 21 words per atom + one uint16 entry per in-cutoff neighbour
+    assert alg(8, 2.5) == pytest.approx(N * (21 * 8 + 2 * nbar(2.5)))
+    head = bench.pick_traffic(entries, N, "f64", 2.5, False, alg(8, 2.5))
+    assert head is not None and head["lj_force_nbr_bytes_per_launch"] >= N * (21 * 8 + 4 * nbar(2.5))   # fp64: above SURVEY's figure too
+    for atoms, dtype, rc, mix, w in ((N, "f64", 3.5, True, 8), (N, "f32", 2.5, False, 4), (1000188, "f64", 2.5, False, 8),
+                                     (N, "f64", 2.5, True, 8), (N, "f64", 3.5, False, 8), (100615028, "f64", 2.5, False, 8)):
+        t = bench.pick_traffic(entries, atoms, dtype, rc, mix, bench.traffic_floor(atoms, w, rc))
+        if t is not None:
+            assert (int(t["atoms"]), t["dtype"], float(t["rc"]), bool(t["mixture"])) == (atoms, dtype, rc, mix)
+            assert t["lj_force_nbr_bytes_per_launch"] >= bench.traffic_floor(atoms, w, rc)
+    # the round-3 mistake, replayed: the single-species figure offered to the mixture line is not taken
+    only_head = [dict(head)]
+    assert bench.pick_traffic(only_head, N, "f64", 3.5, True, alg(8, 3.5)) is None
+    assert bench.pick_traffic(only_head, N, "f32", 2.5, False, alg(4, 2.5)) is None
+    # and an entry that claims less than the algorithmic bytes is refused even on its own key
+    low = [dict(head, lj_force_nbr_bytes_per_launch=int(0.9 * alg(8, 2.5)))]     # (what round 3 attached to the mixture line was 0.56 of its algorithmic bytes)
+    assert bench.pick_traffic(low, N, "f64", 2.5, False, alg(8, 2.5)) is None

@@ -193,6 +193,164 @@ def test_dd_neighbour_rows_are_complete(emdee, oracle, world, ncell):
     dd.close()
 
 
+def _row_sample_check(E, dd, r, tree, L, rlist, nsample, rng):
+    """Rows of a sample of the atoms domain r owns: entries distinct, every one inside r_list of the atom (minimum image of
+    the whole box: 232.6 sigma against 2.8), and as many as the periodic box holds within r_list of that atom (KD-tree of
+    the undivided box) -- together: the row IS the set."""
+    eng = dd.engine(r)
+    gid, xo, _, _ = dd.state(r)
+    n_own = gid.shape[0]
+    x_all = eng.state(velocities=False, forces=False)["positions"]         # owned atoms first, then the ghosts
+    counts, nb = eng.neighbor_lists()
+    assert counts.shape[0] == n_own
+    dx0 = x_all[:n_own] - xo                                               # same atoms in the same order, up to whole box lengths
+    assert float((dx0 - L * torch.round(dx0 / L)).abs().max()) < 1e-6
+    # the atoms nearest to a face of the local box (their rows reach into the ghosts) and a random lot
+    centre = 0.5 * (xo.min(dim=0).values + xo.max(dim=0).values)
+    far = torch.argsort((xo - centre).abs().max(dim=1).values, descending=True)[: nsample // 2]
+    pick = torch.unique(torch.cat([far, torch.from_numpy(rng.integers(0, n_own, nsample // 2)).to(far.device)]))
+    c = counts[pick].long()
+    rows = nb[pick].long()
+    valid = torch.arange(nb.shape[1], device=nb.device)[None, :] < c[:, None]
+    d = x_all[rows.clamp(min=0)] - x_all[pick][:, None, :]
+    d = d - L * torch.round(d / L)                                        # (a ghost may be reported in another image than it is used in)
+    d2 = (d * d).sum(dim=2)
+    assert bool((d2[valid] < rlist * rlist).all()), "an entry outside r_list"
+    srt = torch.where(valid, rows, torch.full_like(rows, -1)).sort(dim=1).values
+    dup = (srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] >= 0)
+    assert not bool(dup.any()), "an entry listed twice"
+    xs = xo[pick].cpu().numpy()
+    xs = xs - L * np.floor(xs / L)
+    want = tree.query_ball_point(xs, rlist, return_length=True, workers=-1) - 1          # (not the atom itself)
+    got = c.cpu().numpy()
+    assert np.array_equal(got, want), "rows of %d sampled atoms differ in length from the undivided box" % int((got != want).sum())
+    del counts, nb, x_all
+    return int(pick.shape[0])
+
+
+def test_full_size_box_in_eight_domains(emdee):
+    """BASELINE configs[2] at the size it is quoted on, on ONE GPU: the 10,061,824-atom box (fcc 136^3 x 4, rho* = 0.8,
+    rc = 2.5 sigma, fp64) cut into 2 x 2 x 2 domains held by one process (the production path but for the transport),
+    against the undivided integrator on the same GPU.  At the load: the same number of listed entries (an integer, exact),
+    the same counted pairs, the same energies; rows of a sample of owned atoms of EVERY domain -- those nearest to a cut
+    face first -- complete against a KD-tree of the periodic box; after 12 steps with displacement-triggered rebuilds: the
+    energies per atom of the undivided run to 1e-9, the same number of rebuilds."""
+    from scipy.spatial import cKDTree
+    E = emdee
+    syn = E.synthetic
+    dev = torch.device("cuda", 0)
+    pos, L = syn.fcc_positions(136)
+    N = pos.shape[0]
+    assert N == 10061824
+    vel = syn.velocities(N)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    nsteps = 12
+    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(RC, RS), E.cu(atoms, dev), skin=SKIN)
+    listed_md, pairs_md, e_md0 = md.nbr_stats()["listed"], md.count_pairs(), md.totals()
+    md.step_(nsteps, DT)
+    e_md1, builds_md = md.totals(), md.nbr_stats()["builds"]
+    md.close()
+    del md
+    torch.cuda.empty_cache()
+
+    world = 8
+    dd = _build(E, world, pos, vel, atoms, L, scatter=False)
+    c = [dd.counts(r) for r in range(world)]
+    assert sum(k["n_owned"] for k in c) == N and all(k["n_ghost"] > 0.1 * k["n_owned"] for k in c)
+    assert sum(dd.engine(r).nbr_stats()["listed"] for r in range(world)) == listed_md
+    assert abs(2 * sum(dd.engine(r).count_pairs() for r in range(world)) - 2 * pairs_md) <= 2 * world
+    e0 = dd.totals()
+    assert e0[0] / N == pytest.approx(e_md0[0] / N, rel=1e-9) and e0[1] / N == pytest.approx(e_md0[1] / N, rel=1e-9)
+    xw = pos - L * np.floor(pos / L)
+    xw[xw >= L] = 0.0
+    tree = cKDTree(xw, boxsize=L)
+    rng = np.random.default_rng(3)
+    checked = sum(_row_sample_check(E, dd, r, tree, L, RC + SKIN, 1600, rng) for r in range(world))
+    assert checked > 8000
+    del tree, xw
+    dd.step_(nsteps, DT, 0)
+    e1 = dd.totals()
+    assert e1[0] / N == pytest.approx(e_md1[0] / N, rel=1e-9) and e1[1] / N == pytest.approx(e_md1[1] / N, rel=1e-9)
+    # (the undivided count includes the load; a request raised by the last step is served inside the call by the
+    # decomposition, at the next call by the undivided integrator)
+    assert builds_md - 1 >= 1 and 0 <= dd.stats()["rebuilds"] - (builds_md - 1) <= 1
+    assert dd.rebuild_stats()["count_free"] >= 1
+    dd.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("config", ["fp32", "mixture_rc35"])
+def test_full_size_box_in_two_domains(emdee, capfd, monkeypatch, config):
+    """BASELINE configs[3] and configs[4] at full size through the decomposition (two domains in one process): fp32 storage
+    and pair math at rc = 2.5 sigma; the binary mixture at rc = 3.5 sigma in fp64, which must be stepped by the TYPED
+    kernels (csrc/typed.hpp) in both domains.  Size-independent properties, as in tests/test_gpu_parity.py for the undivided
+    boxes: every atom owned once, counted pairs against nbar(rc), Newton's third law over the owned rows, energy and
+    momentum over displacement-triggered rebuilds."""
+    E = emdee
+    syn = E.synthetic
+    dev = torch.device("cuda", 0)
+    pos, L = syn.fcc_positions(136)
+    N = pos.shape[0]
+    vel = syn.velocities(N)
+    mixture = config == "mixture_rc35"
+    rc, rs = (3.5, 3.0) if mixture else (2.5, 2.0)
+    dtype = torch.float64 if mixture else torch.float32
+    if mixture:
+        eps, sigma = syn.mixture_parameters(syn.mixture_types(N))
+        atoms = E.lennard_jones_atoms(eps, sigma)
+    else:
+        atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+    capfd.readouterr()
+    world = 2
+    dd = E.DomainDecomposition([L] * 3, E.domain.rank_grid(world), E.LennardJonesModel(rc, rs), skin=SKIN, dtype=dtype, device=dev)
+    ndt = np.float64 if mixture else np.float32
+    for r in range(world):
+        mine = np.arange(N)[(np.arange(N) * world) // N == r]
+        dd.set_atoms_(r, E.cu(pos[mine].astype(ndt), dev), E.cu(vel[mine].astype(ndt), dev), E.cu(atoms[mine], dev),
+                      torch.from_numpy(mine.astype(np.int64)).to(dev))
+    dd.load_()
+    del pos, vel
+    err = capfd.readouterr().err
+    if mixture:
+        assert err.count("typed kernels on") >= 2, err[-600:]              # both domains
+    else:
+        assert "typed kernels on" not in err
+    c = [dd.counts(r) for r in range(world)]
+    assert sum(k["n_owned"] for k in c) == N and c[0]["n_global"] == N
+    nbar = (4.0 / 3.0) * np.pi * rc ** 3 * 0.8
+    pairs = sum(dd.engine(r).count_pairs() for r in range(world))
+    assert abs(pairs / (0.5 * N) - nbar) < (6.0 if mixture else 3.0), pairs / (0.5 * N)
+    ftot, fmax, ptot0 = torch.zeros(3, dtype=torch.float64, device=dev), 0.0, torch.zeros(3, dtype=torch.float64, device=dev)
+    for r in range(world):
+        _, _, v, f = dd.state(r)
+        ftot += f.double().sum(dim=0); fmax = max(fmax, f.abs().max().item()); ptot0 += v.double().sum(dim=0)
+        del v, f
+    assert ftot.abs().max().item() < (1e-6 if mixture else 1e-3) * fmax * N ** 0.5      # Newton's third law across the cut
+    e0 = dd.totals()
+    nsteps = 24
+    dd.step_(nsteps, DT, 0)
+    e1 = dd.totals()
+    err = capfd.readouterr().err
+    if mixture:
+        assert "typed kernels off" not in err, err[-600:]
+    drift = ((e1[0] + e1[1]) - (e0[0] + e0[1])) / abs(e0[0] + e0[1])
+    assert abs(drift) < (3e-4 if mixture else 5e-5), drift
+    ptot = torch.zeros(3, dtype=torch.float64, device=dev)
+    for r in range(world):
+        _, _, v, _ = dd.state(r)
+        ptot += v.double().sum(dim=0)
+        del v
+    assert (ptot - ptot0).abs().max().item() < (1e-9 if mixture else 2e-3) * N ** 0.5 * 10
+    st = dd.stats()
+    assert st["rebuilds"] >= 2 and dd.rebuild_stats()["count_free"] >= 1
+    assert 2.0 * e1[1] / (3 * N - 3) > 0.4
+    pairs1 = sum(dd.engine(r).count_pairs() for r in range(world))
+    assert abs(pairs1 / (0.5 * N) - nbar) < (5.0 if mixture else 2.0), pairs1 / (0.5 * N)
+    dd.close()
+    torch.cuda.empty_cache()
+
+
 def test_dd_langevin_single_call_matches_oracle(emdee, oracle):
     """Noise keyed by global atom id and step number: the decomposed run draws what the undivided run draws."""
     E = emdee
