@@ -548,18 +548,18 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
         }
         q.w = __int_as_float(gp);
-        tile[s] = q;
+        if (EMDEE_BOUND(BS_BUILD_TILE, s, a.tile_cap)) tile[s] = q;
     });
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own)
+        if (o < n_own && EMDEE_BOUND(BS_BUILD_OWN, o, a.own_cap))
             T.oinfo[o] = make_int2(own_p[k], (own_oc[k] << 20) | (own_sub(own_oc[k], own_ti[k]) << 17) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         const int oc = brick_locate(T, o, ti, p);
-        T.oinfo[o] = make_int2(p, (oc << 20) | (own_sub(oc, ti) << 17) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+        if (EMDEE_BOUND(BS_BUILD_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (oc << 20) | (own_sub(oc, ti) << 17) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
     // candidate rows per own cell (and sub-bin): the 9 tile rows (dy, dz) of 3 cells around it, as {first tile slot, slots};
     // the last entry is empty (atoms that own no row).  One table per brick instead of index arithmetic and two reads per
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     epF++;
                 }
             }
-            if (have) {
+            if (have && EMDEE_BOUND(BS_BUILD_ROW, p, a.n)) {
                 constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
                 // (left to itself the compiler interleaves two trips of this loop behind a run-time alias check and splits each
                 // 16-byte store into four: 130 instructions per atom where 40 do -- the flush was 0.32 ms of the build for that)
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
 #ifdef EMDEE_BUILD_ABLATE
             if (have && !(EMDEE_BUILD_ABLATE & 4)) {
 #else
-            if (have) {
+            if (have && EMDEE_BOUND(BS_BUILD_ROW, p, a.n)) {
 #endif
                 constexpr int BLKL = EPL * GL;                // entries per lane-major block of the force kernels' rows
                 EMDEE_PLAIN_LOOP
@@ -1154,11 +1154,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     const int k = __ffs((int)W) - 1;
                     W &= W - 1;
                     const int c = k + (k >= BUILD2_FIELD ? cB : cA);
-                    if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
+                    if (e < ustride && EMDEE_BOUND(BS_BUILD_ROWBUF, row_position<GL>(e), ustride)) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
                     e++;
                 }
             }
-            if (have) {
+            if (have && EMDEE_BOUND(BS_BUILD_ROW, p, a.n)) {
                 for (int c = gl * EPL; c < a.stride; c += G * EPL)
                     *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
                 if (gl == G - 1) {                            // the last lane's inclusive prefix is the row length
@@ -1197,13 +1197,13 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     const unsigned bits = (half >> gshift) & gmask;
                     if (pass) {
                         const unsigned e = count + __popc(bits & ltmask);
-                        if (e < ustride) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
+                        if (e < ustride && EMDEE_BOUND(BS_BUILD_ROWBUF, row_position<GL>(e), ustride)) rowbuf[row_position<GL>(e)] = (unsigned short)(c << a.idx_shift);
                     }
                     count += __popc(bits);
                 }
             }
         }
-        if (have) {
+        if (have && EMDEE_BOUND(BS_BUILD_ROW, p, a.n)) {
             for (int c = gl * EPL; c < a.stride; c += G * EPL)
                 *reinterpret_cast<uint4 *>(row + c) = *reinterpret_cast<const uint4 *>(rowbuf + c);
             if (gl == 0) {
@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
         }
         if (FAST && a.uni.inv_sigma != (real)1) { r.x *= a.uni.inv_sigma; r.y *= a.uni.inv_sigma; r.z *= a.uni.inv_sigma; }
+        if (!EMDEE_BOUND(BS_FORCE_TILE, s, SOA ? SOA_SLOTS : a.tile_cap)) return;
         if (SOA) { plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z; }
         else tile[s] = r;
         if (sizeof(real) == 4 && !SOA) tile_te[s] = a.te[gp];
@@ -1303,12 +1304,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], (own_m[k] << 16) | own_ti[k]);
+        if (o < n_own && EMDEE_BOUND(BS_FORCE_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(own_p[k], (own_m[k] << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         brick_locate(T, o, ti, p);
-        T.oinfo[o] = make_int2(p, (a.cnt[p] << 16) | ti);
+        if (EMDEE_BOUND(BS_FORCE_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (a.cnt[p] << 16) | ti);
     }
     __syncthreads();
 

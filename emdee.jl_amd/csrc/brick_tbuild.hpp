@@ -97,7 +97,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? EMDEE_TB_WAVES : 4)) voi
         q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
         q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
         q.w = __int_as_float(gp);
-        tile[s] = q;
+        if (EMDEE_BOUND(BS_BUILD_TILE, s, a.tile_cap)) tile[s] = q;
     });
     __syncthreads();
 
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? EMDEE_TB_WAVES : 4)) voi
 #pragma unroll 1
         for (int r = 0; r < NRUN; r++) {
             const int c0r = __builtin_amdgcn_readlane(c0, r), spr = __builtin_amdgcn_readlane(span, r), pr = __builtin_amdgcn_readlane(pex, r);
-            for (int k = lane; k < spr; k += WAVE) wscr[pr + k] = (unsigned short)(c0r + k);
+            for (int k = lane; k < spr; k += WAVE)
+                if (EMDEE_BOUND(BS_TBUILD_CAND, pr + k, NSEG * TB_SEG)) wscr[pr + k] = (unsigned short)(c0r + k);
         }
         // my candidates: segment j, lane l <-> candidate 64 j + l
         f32x2 X[NPAIR], Y[NPAIR], Z[NPAIR];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? EMDEE_TB_WAVES : 4)) voi
                 *reinterpret_cast<uint4 *>(dst) = q;
             };
             unsigned short *rows = a.nbr + (size_t)pfirst * stride;
+            if (!EMDEE_BOUND(BS_BUILD_ROW, pfirst + nb - 1, a.n)) return;
             if (B > 1) {
                 if (f_rb < nb) chunk(wscr + f_src, rows + f_dst);
             } else {

@@ -508,3 +508,9 @@ int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap) {
 }
 
 }  // extern "C"
+
+#ifdef EMDEE_BOUNDS
+namespace emdee {
+void bounds_poll_capi(int out[3]) { bounds_poll_here(out); }
+}  // namespace emdee
+#endif

@@ -42,11 +42,74 @@ struct Failure {
         }                                                                                        \
     } while (0)
 
+// ---- bounds-checked device build (make BOUNDS=1 -> libemdee_hip_bounds.so) ------------------------------
+// Every device-side write (and list read) whose index comes from DATA -- counts, prefix sums, slots -- into a buffer sized
+// by a CAPACITY goes through EMDEE_BOUND(site, index, capacity): in the product build that is `true` and costs nothing; in
+// the bounds build an index outside [0, capacity) is NOT used, the first such event is recorded in a sticky device word of
+// the translation unit, and every C-ABI call from then on returns EMDEE_ERR_OVERFLOW with the site, index and capacity in
+// emdee_last_error() -- an error message where the product build would fault (round 3: SIGABRT of the host process).
+enum BoundSite {
+    BS_NONE = 0, BS_BUILD_TILE = 1, BS_BUILD_OWN = 2, BS_BUILD_ROWBUF = 3, BS_BUILD_ROW = 4, BS_FORCE_TILE = 5, BS_FORCE_OWN = 6,
+    BS_TYPED_TILE = 7, BS_TYPED_OWN = 8, BS_TYPED_ROWBUF = 9, BS_TYPED_ROW = 10, BS_DD_MIG_PACK = 11, BS_DD_ASSEMBLE = 12,
+    BS_DD_GHOST_PACK = 13, BS_DD_GHOST_UNPACK = 14, BS_DD_STEP_PACK = 15, BS_DD_STEP_UNPACK = 16, BS_CELL_SCATTER = 17,
+    BS_TBUILD_CAND = 18, BS_TBUILD_ROWBUF = 19, BS_PART_SCATTER = 20, BS_COUNT = 21
+};
+static inline const char *bound_site_name(int s) {
+    static const char *names[BS_COUNT] = {"none", "build: tile slot", "build: own-atom table", "build: row buffer", "build: row of the list",
+        "force: tile slot", "force: own-atom table", "typed build: tile slot", "typed build: own-atom table", "typed build: row buffer",
+        "typed build: row of the list", "dd: migrant message", "dd: assembled owned arrays", "dd: ghost send list", "dd: ghost rows",
+        "dd: step message", "dd: step unpack", "cells: scatter", "transposed build: candidate table", "transposed build: row buffer",
+        "partition: scatter"};
+    return (s > 0 && s < BS_COUNT) ? names[s] : "unknown site";
+}
+#ifdef EMDEE_BOUNDS
+static __device__ int g_bounds_word[4];                // {site, index (clamped to int), capacity, 0}: first event wins, never cleared
+__device__ static inline bool bound_ok(int site, long long idx, long long cap) {
+    if (idx >= 0 && idx < cap) return true;
+    if (atomicCAS(&g_bounds_word[0], 0, site) == 0) {
+        g_bounds_word[1] = (int)(idx > 2147483647LL ? 2147483647LL : (idx < -2147483647LL ? -2147483647LL : idx));
+        g_bounds_word[2] = (int)(cap > 2147483647LL ? 2147483647LL : cap);
+    }
+    return false;
+}
+#define EMDEE_BOUND(site, idx, cap) (::emdee::bound_ok((site), (long long)(idx), (long long)(cap)))
+// the sticky word of THIS translation unit (each .hip file defines one poll function with it; capi.hip asks all of them)
+static inline void bounds_poll_here(int out[3]) {
+    int w[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(w, HIP_SYMBOL(g_bounds_word), sizeof(w)) == hipSuccess) {
+        out[0] = w[0]; out[1] = w[1]; out[2] = w[2];
+    } else {
+        (void)hipGetLastError();
+        out[0] = out[1] = out[2] = 0;
+    }
+}
+void bounds_poll_f32(int out[3]);
+void bounds_poll_f64(int out[3]);
+void bounds_poll_capi(int out[3]);
+static inline void bounds_raise_if_set() {
+    int w[3];
+    void (*polls[3])(int *) = {bounds_poll_f64, bounds_poll_f32, bounds_poll_capi};
+    for (auto poll : polls) {
+        poll(w);
+        if (w[0] != 0) {
+            set_error("device bounds check (%s): index %d outside capacity %d -- the access was skipped; results from here on are not to be used",
+                      bound_site_name(w[0]), w[1], w[2]);
+            throw Failure{EMDEE_ERR_OVERFLOW};
+        }
+    }
+}
+#else
+#define EMDEE_BOUND(site, idx, cap) (true)
+#endif
+
 // Wrap a C-ABI entry point body: translates Failure / std::exception into a status code.
 template <class F>
 static inline int32_t guarded(F &&body) {
     try {
         body();
+#ifdef EMDEE_BOUNDS
+        bounds_raise_if_set();
+#endif
         return EMDEE_OK;
     } catch (const Failure &f) {
         return f.code;

@@ -744,6 +744,12 @@ struct DdImpl : IDd {
         if (mig_cap_forced > 0) mig = mig_cap_forced;
         d.mig_caps.npeers = d.gs_caps.npeers = d.gr_caps.npeers = np;
         d.mig_caps.start[0] = d.gs_caps.start[0] = d.gr_caps.start[0] = 0;
+        d.mig_caps.debug_inject = d.gs_caps.debug_inject = d.gr_caps.debug_inject = 0;
+#ifdef EMDEE_BOUNDS
+        // the checker's own test: pack ghost rows with the send list indexed by the counts although a message overflowed
+        // (what k_dd_pack_ghost_rows_padded did before 2d85cf1 -- an out-of-range index the bounds build must report, not use)
+        if (const char *e = std::getenv("EMDEE_BOUNDS_INJECT")) d.gs_caps.debug_inject = std::string(e) == "ghost_pack" ? 1 : 0;
+#endif
         for (int p = 0; p < np; p++) {
             d.mig_caps.start[p + 1] = d.mig_caps.start[p] + mig;
             d.gs_caps.start[p + 1] = d.gs_caps.start[p] + ghost_cap(d.plan.send_start[p + 1] - d.plan.send_start[p]);

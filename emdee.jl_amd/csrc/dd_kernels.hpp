@@ -259,6 +259,7 @@ constexpr int DD_RHDR = 16;
 struct DdCaps {
     int npeers;
     int start[DD_MAX_PEERS + 1];       // rows: message p holds slots [start[p], start[p+1]) of the padded buffer
+    int debug_inject;                  // bounds build only (EMDEE_BOUNDS_INJECT=ghost_pack): pack ghost rows although a message overflowed
 };
 __host__ __device__ static inline size_t dd_pad_begin(const DdCaps &c, int p, size_t row) { return (size_t)(p + 1) * DD_RHDR + (size_t)c.start[p] * row; }
 static inline size_t dd_pad_msg_begin(const DdCaps &c, int p, size_t row) { return (size_t)p * DD_RHDR + (size_t)c.start[p] * row; }
@@ -291,6 +292,7 @@ __global__ void k_dd_pack_migrants_padded(DdCaps caps, const int *__restrict__ b
     if (t >= caps.start[caps.npeers]) return;
     const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
     if (slot >= bin_start[2 + p] - bin_start[1 + p]) return;
+    if (!EMDEE_BOUND(BS_DD_MIG_PACK, slot, caps.start[p + 1] - caps.start[p])) return;
     const int i = ids[bin_start[1 + p] + slot];
     MigRow<real> r;
 #pragma unroll
@@ -343,6 +345,7 @@ __global__ void k_dd_assemble_padded(int n_max, DdCaps caps, const int *__restri
     }
     int a = k - n_stay, p = 0;
     while (p + 1 < caps.npeers && a >= w[DDW_ARRIVE + p]) { a -= w[DDW_ARRIVE + p]; p++; }
+    if (!EMDEE_BOUND(BS_DD_ASSEMBLE, k, n_max)) return;
     const MigRow<real> r = reinterpret_cast<const MigRow<real> *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[a];
 #pragma unroll
     for (int d = 0; d < 3; d++) { x2[3 * (size_t)k + d] = r.x[d]; v2[3 * (size_t)k + d] = r.v[d]; }
@@ -368,11 +371,13 @@ __global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__
     }
     // an overflow anywhere: the rebuild will be redone with counts and no row of this one is looked at -- and the send
     // list (ids, bins, codes: sized by the capacities) does not hold what the counts say
-    if (over || t >= caps.start[caps.npeers]) return;
+    // (bounds build, test of the checker itself: debug_inject puts the pre-2d85cf1 behaviour back -- the list indexed by the counts)
+    if ((over && !caps.debug_inject) || t >= caps.start[caps.npeers]) return;
     const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
     if (slot >= peer_count[p]) return;
     int k = slot;
     for (int q = 0; q < p; q++) k += peer_count[q];
+    if (!EMDEE_BOUND(BS_DD_GHOST_PACK, k, caps.start[caps.npeers])) return;   // the send list (ids, bins, codes) holds start[npeers] entries
     const int i = ids[k], dir = g.bin_dir[bins[k]];
     GhostRow<real> r;
 #pragma unroll

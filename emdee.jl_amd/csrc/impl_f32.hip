@@ -5,3 +5,9 @@
 namespace emdee {
 template struct Factory<float>;
 }
+
+#ifdef EMDEE_BOUNDS
+namespace emdee {
+void bounds_poll_f32(int out[3]) { bounds_poll_here(out); }
+}  // namespace emdee
+#endif

@@ -62,3 +62,9 @@ void dd_describe(const double len[3], const int32_t grid[3], double halo, int ra
     for (int d = 0; d < 3; d++) { local_lo[d] = geo.local_lo[d]; local_len[d] = geo.local_len[d]; periodic[d] = geo.periodic[d]; }
 }
 }  // namespace emdee
+
+#ifdef EMDEE_BOUNDS
+namespace emdee {
+void bounds_poll_f64(int out[3]) { bounds_poll_here(out); }
+}  // namespace emdee
+#endif

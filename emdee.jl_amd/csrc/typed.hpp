@@ -311,17 +311,17 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
         q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
         q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
         q.w = __int_as_float(gp);
-        tile[s] = q;
+        if (EMDEE_BOUND(BS_TYPED_TILE, s, a.tile_cap)) tile[s] = q;
     });
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own) T.oinfo[o] = make_int2(own_p[k], (own_q[k] << 20) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
+        if (o < n_own && EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(own_p[k], (own_q[k] << 20) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {
         int ti, p;
         const int q = typed_locate(T, o, ti, p);
-        T.oinfo[o] = make_int2(p, (q << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+        if (EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (q << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
     // candidate rows per own cell: for each neighbour species the 9 tile rows of 3 cells around it, {first tile slot, slots};
     // entry NOC is empty (atoms that own no row)
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
                 }
             }
         }
-        if (have) {
+        if (have && EMDEE_BOUND(BS_TYPED_ROW, p, a.n)) {
             // (left to itself the compiler interleaves two trips of this loop behind a run-time alias check and splits each
             // 16-byte store into four: 130 instructions per atom where 40 do -- the flush was 0.32 ms of the build for that)
             EMDEE_PLAIN_LOOP
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
             r.y += (real)(((sh >> 2) & 3) - 1) * a.g.len[1];
             r.z += (real)(((sh >> 4) & 3) - 1) * a.g.len[2];
         }
-        plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z;
+        if (EMDEE_BOUND(BS_TYPED_TILE, s, PITCH)) { plane[s] = r.x; plane[PITCH + s] = r.y; plane[2 * PITCH + s] = r.z; }
     });
     if (tid == 0) {   // the sentinel record every unused row entry points at: fails r2 < rc2, never NaN
         const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
@@ -593,11 +593,12 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own) { T.oinfo[o] = make_int2(own_p[k] | ((own_q[k] / NOC) << 30), own_ti[k]); T.ocnt[o] = own_m[k]; }
+        if (o < n_own && EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) { T.oinfo[o] = make_int2(own_p[k] | ((own_q[k] / NOC) << 30), own_ti[k]); T.ocnt[o] = own_m[k]; }
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {
         int ti, p;
         const int q = typed_locate(T, o, ti, p);
+        if (!EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) continue;
         T.oinfo[o] = make_int2(p | ((q / NOC) << 30), ti);
         T.ocnt[o] = a.cnt[p];
     }
