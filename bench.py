@@ -186,12 +186,15 @@ def self_launch(args, budget=None):
         limit = budget.limit(args.launch_timeout if args.launch_timeout > 0 else 1e9, reserve=3.0)
         child = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, text=True)   # its own process group: killable as a whole
 
+        held = []
+
         def relay():
             for ln in child.stdout:
                 if is_result_line(ln):
-                    if printed:                                                  # ONE line, whatever the ranks do
+                    if printed or held:                                          # ONE line, whatever the ranks do
                         continue
-                    printed.append(ln)
+                    held.append(ln)                                              # printed when the rank group has ended: it carries its status
+                    continue
                 sys.stdout.write(ln)
                 sys.stdout.flush()
         t = threading.Thread(target=relay, daemon=True)
@@ -216,6 +219,23 @@ def self_launch(args, budget=None):
             child.wait()
             rc = 124
         t.join(timeout=5.0)
+        if held:
+            # The measurement is complete once its line exists, whatever happens to the ranks afterwards (target-box leg,
+            # teardown, a barrier): the line is kept -- but a rank group that then ends abnormally (a crash, a GPU fault, a
+            # stop at the deadline) must show in the run's records, not only on stderr: top-level "exit_status".
+            ln = held[0]
+            try:
+                d = json.loads(ln)
+                d["exit_status"] = rc
+                ln = json.dumps(d) + "\n"
+            except ValueError:
+                pass
+            if rc != 0:
+                print("bench.py: the rank group ended with status %d AFTER its result line was out; the line carries exit_status"
+                      % rc, file=sys.stderr)
+            printed.append(ln)
+            sys.stdout.write(ln)
+            sys.stdout.flush()
         return rc
 
     rc = run([])
@@ -511,6 +531,13 @@ def main():
         overlap = halo_mode["chosen"] == "overlapped"
     builds0 = engine.nbr_stats()["builds"]
     engine.profile_(True)
+    native_dd = domain is not None and dd_engine is not None and dd_engine.startswith("native")
+    local_engines = [engine]
+    if native_dd and world == 1:                         # every domain lives in this process: time them all
+        local_engines = [domain.engine(l) for l in range(args.domains)]
+        for e in local_engines[1:]:
+            e.profile_(True)
+    phase0 = domain.phase_times() if native_dd else None
     fence()
     t0 = time.perf_counter()
     run(args.steps)
@@ -522,6 +549,31 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+
+    # ---- where a rank's step goes (N > 1, native decomposition): means per timed step of the fused launches over interior and
+    # boundary bricks, the halo (pack -> exchange -> unpack, on the stream it runs on: the wait of the boundary half), the
+    # engine's sort + list, the host wall-clock inside rebuilds and inside blocking read-backs, and the ghost share;
+    # every rank's figures, gathered to rank 0 -- so that a scaling curve explains itself the day it is measured
+    per_rank = None
+    if native_dd:
+        phase1 = domain.phase_times()
+        mine = []
+        for l, e in enumerate(local_engines):
+            per = lambda name: e.kernel_time(name)[0] / args.steps
+            c = domain.counts(l)
+            mine.append({"rank": rank if world > 1 else l, "atoms_owned": c["n_owned"], "ghost_fraction": c["n_ghost"] / max(c["n_owned"] + c["n_ghost"], 1),
+                         "force_interior_ms": per("fused_step_interior"), "force_boundary_ms": per("fused_step_boundary"),
+                         "halo_ms": per("halo"), "rebuild_device_ms": per("rebuild"),
+                         "rebuild_wall_ms": (phase1["rebuild_ms"] - phase0["rebuild_ms"]) / args.steps,
+                         "readback_wall_ms": (phase1["readback_ms"] - phase0["readback_ms"]) / args.steps,
+                         "readbacks": phase1["readbacks"] - phase0["readbacks"], "rebuilds": phase1["rebuilds"] - phase0["rebuilds"]})
+        ranks = mine
+        if dist is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            ranks = [r for g in gathered for r in g]
+        per_rank = {"unit": "ms per timed step (means); rebuild_wall / readback_wall: host wall-clock of the process, shared by its domains",
+                    "ranks": ranks}
 
     plain_ms, plain_launches = engine.kernel_time("lj_force_nbr")
     fused_ms, fused_launches = engine.kernel_time("lj_force_nbr_fused_step")
@@ -598,6 +650,8 @@ def main():
                           "max_count": stats["max_count"], "capacity": stats["capacity"]},
         "energy_per_atom": {"potential": ep / N_energy, "kinetic": ek / N_energy},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if degraded is not None and world > 1 and not (dd_engine or "").startswith("native"):
         out["degraded"] = degraded     # the native decomposition (north_star's) did not produce this line
     if rank == 0:

@@ -99,6 +99,7 @@ SIGNATURES = {
     "emdee_dd_set_langevin": [_p, _dbl, _dbl, C.c_uint64, C.c_uint64],
     "emdee_dd_stats": [_p, C.POINTER(_i64)],
     "emdee_dd_rebuild_stats": [_p, C.POINTER(_i64)],
+    "emdee_dd_phase_times": [_p, C.POINTER(_dbl)],
     "emdee_dd_set_overlap": [_p, _i32],
     "emdee_last_error": [],
 }

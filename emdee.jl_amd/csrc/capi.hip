@@ -503,6 +503,9 @@ int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]) {
 int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]) {
     return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->rebuild_stats(out); });
 }
+int32_t emdee_dd_phase_times(emdee_dd *dd, double out[8]) {
+    return guarded([&] { REQUIRE_PTR(dd, "dd"); REQUIRE_PTR(out, "out"); dd->impl->phase_times(out); });
+}
 int32_t emdee_dd_set_overlap(emdee_dd *dd, int32_t overlap) {
     return guarded([&] { REQUIRE_PTR(dd, "dd"); dd->impl->set_overlap(overlap != 0); });
 }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -136,6 +137,8 @@ struct emdee_ctx {
                                      // [POST_DATA, POST_DATA + POST_MAX) + stamp at POST_STAMP: read-backs posted by a kernel
     int32_t *post_dev = nullptr;     // the same memory as the device sees it
     uint32_t post_seq = 0;           // (EMDEE_READBACK=copy: every read-back as copy + synchronize, A/B)
+    double readback_ms = 0.0;        // host wall-clock spent in blocking read-backs, and how many (emdee_dd_phase_times)
+    int64_t readbacks = 0;
 };
 
 namespace emdee {
@@ -204,6 +207,12 @@ static __global__ void k_post_words(const int *__restrict__ src, int n, volatile
 static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev, int n, int32_t *out) {
     EMDEE_REQUIRE(n >= 0 && n <= POST_MAX, EMDEE_ERR_INVALID, "read_back_words: %d words", n);
     if (n == 0) return;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Clock {
+        emdee_ctx *c;
+        std::chrono::steady_clock::time_point t0;
+        ~Clock() { c->readback_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->readbacks++; }
+    } clock{ctx, t_begin};
     int32_t *data = ctx->host_flags + POST_DATA;
     // (EMDEE_READBACK is looked at per call, not per context: a process may hold one context for its whole life)
     const char *form = std::getenv("EMDEE_READBACK");
@@ -217,7 +226,16 @@ static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev
                            (volatile int *)(ctx->post_dev + POST_STAMP), seq);
         volatile int32_t *stamp = ctx->host_flags + POST_STAMP;
         for (unsigned spins = 1; *stamp != seq; spins++) {
+            __builtin_ia32_pause();                                        // (the sibling hyper-thread may be another rank's host thread)
             if ((spins & 0x3fffu) == 0) {                                  // a stream that failed would never stamp
+                // A stream that is blocked, not failed (a peer's message that has not arrived yet), can keep us here for
+                // long: after ~2 ms of spinning the core is given up and the stream is waited for the ordinary way; the
+                // 6 us fast path of a short queue is untouched.
+                if (std::chrono::steady_clock::now() - t_begin > std::chrono::milliseconds(2)) {
+                    EMDEE_HIP_CHECK(hipStreamSynchronize(s));
+                    EMDEE_REQUIRE(*stamp == seq, EMDEE_ERR_HIP, "read-back: the stream drained without posting its words");
+                    break;
+                }
                 const hipError_t q = hipStreamQuery(s);
                 if (q == hipSuccess) {
                     EMDEE_REQUIRE(*stamp == seq, EMDEE_ERR_HIP, "read-back: the stream drained without posting its words");

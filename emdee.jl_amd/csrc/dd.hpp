@@ -201,6 +201,8 @@ struct Domain {
     hipStream_t comm = nullptr;          // communication stream
     hipStream_t side = nullptr;          // boundary bricks: unpack + second launch of a step, concurrent with the interior launch's tail
     hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_bnd = nullptr;
+    bool halo_timed = false;             // T_HALO pair of the step in flight (in-order / in-process forms)
+    size_t halo_tk = 0;
     std::unique_ptr<MdImpl<real>> md;
     // caller-order working arrays (owned first, then ghosts for x and atoms), double-buffered across a migration
     DevBuf<real> x, x2, v, v2, f;
@@ -614,6 +616,12 @@ struct DdImpl : IDd {
             explicit Scope(bool &b) : f(b) { f = true; }
             ~Scope() { f = false; }
         } scope(in_rebuild);
+        struct Wall {
+            double &ms;
+            int64_t &n;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            ~Wall() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); n++; }
+        } wall{stat_rebuild_wall_ms, stat_rebuild_calls};
         join_halo();
         if (world == 1 && from_engines && !no_shortcut) {
             // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
@@ -628,7 +636,13 @@ struct DdImpl : IDd {
         }
         // ---- 0. caller-order copies of the integrated state
         bool unsorted = false;
-        if (from_engines && count_free && dom[0]->have_caps) {
+        // The count-free protocol rests on every rank neighbouring every other one: the overflow word and the error word of a
+        // rank reach everybody in the SAME exchange (message headers), so all commit or all redo.  Today that follows from
+        // the <= 3 bricks per dimension of DdGeom::init; should that limit ever go, a far rank would commit while its
+        // neighbours redo -- so the dependency is checked here, and such a grid takes the counted rebuild.
+        bool all_neighbours = true;
+        for (auto &pd : dom) all_neighbours = all_neighbours && pd->geo.npeers == world - 1;
+        if (from_engines && count_free && all_neighbours && dom[0]->have_caps) {
             if (redistribute_count_free(with_forces)) return;
             unsorted = true;                                        // a capacity was exceeded somewhere: everybody redoes it with counts
             stat_fallback++;
@@ -860,7 +874,7 @@ struct DdImpl : IDd {
             hipLaunchKernelGGL((k_dd_ghost_counts<real>), dim3(1), dim3(64), 0, d.stream(), d.gs_caps, d.gr_caps, d.small.ptr + 33,
                                d.recvbuf.ptr, d.w.ptr);
             read_back_words(d.ctx, d.stream(), d.w.ptr, DDW_COUNT, d.host_w);
-            EMDEE_REQUIRE(d.host_w[DDW_ERR] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom of domain %d left the neighbourhood of its brick", d.geo.rank);
+            EMDEE_REQUIRE(d.host_w[DDW_ERR] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom left the neighbourhood of its brick (seen by domain %d: its own atom or a peer's -- the word travels with the ghost messages, every rank fails here together)", d.geo.rank);
             over = over || d.host_w[DDW_OVER] != 0;
         }
         // the same word on every rank (k_dd_ghost_counts): ranks in separate processes have nothing but that to agree on the
@@ -944,6 +958,8 @@ struct DdImpl : IDd {
         force_inline = true;
         EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_packed, 0));
         const int np = d.geo.npeers;
+        const bool timed = d.sys().profiling;
+        const size_t tk = timed ? d.sys().timers[T_HALO].begin(d.side) : 0;
         hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(std::max(d.n_send, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
                            d.n_send, d.plan, d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr,
                            d.V(vj), d.sendbuf.ptr);
@@ -956,6 +972,7 @@ struct DdImpl : IDd {
         exchange();                                                        // in order on the halo stream
         hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(std::max(d.n_ghost, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
                            d.n_ghost, d.n_owned, d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
+        if (timed) d.sys().timers[T_HALO].end(tk, d.side);
         d.md->current_mask = 0;
         compute(d, 2);
         EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
@@ -974,6 +991,8 @@ struct DdImpl : IDd {
             Domain<real> &d = *pd;
             const int np = d.geo.npeers;
             const int nthreads = std::max(d.n_send, std::max(np, 1));
+            d.halo_timed = d.sys().profiling;
+            if (d.halo_timed) d.halo_tk = d.sys().timers[T_HALO].begin(d.stream());
             hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_send, d.plan,
                                d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr, d.V(vj),
                                d.sendbuf.ptr);
@@ -1013,6 +1032,7 @@ struct DdImpl : IDd {
                 const int nthreads = std::max(d.n_ghost, std::max(d.geo.npeers, 1));
                 hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_ghost, d.n_owned,
                                    d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
+                if (d.halo_timed) d.sys().timers[T_HALO].end(d.halo_tk, d.stream());
                 d.md->current_mask = 0;
                 compute(d, overlap ? 2 : 0);
                 if (aside) EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
@@ -1147,7 +1167,11 @@ struct DdImpl : IDd {
                 const bool tiled = d.sys().brick_active && d.sys().n_total > 0;
                 if (tiled && ((B - ran) & 1)) d.sys().swap_step_buffers();   // the cancelled launches did not advance the ping-pong
                 if (d.sys().lgv_on && d.sys().n_total > 0) d.sys().lgv_step -= (unsigned long long)(B - ran);
-                if (tiled && d.sys().profiling) d.sys().timers[T_STEP].dropped += (overlap ? 2 : 1) * (B - ran);
+                if (tiled && d.sys().profiling) {
+                    d.sys().timers[T_STEP].dropped += B - ran;
+                    if (overlap) d.sys().timers[T_STEP_BOUNDARY].dropped += B - ran;
+                    d.sys().timers[T_HALO].dropped += B - ran;
+                }
                 if (!tiled && d.sys().profiling && d.sys().n_total > 0) {
                     d.sys().timers[T_FORCE].dropped += B - ran;
                     d.sys().timers[T_KICK_DRIFT].dropped += B - ran;
@@ -1225,6 +1249,23 @@ struct DdImpl : IDd {
     }
     void stats(int64_t out[4]) override {
         out[0] = stat_rebuilds; out[1] = stat_batches; out[2] = stat_cancelled; out[3] = stat_migrated;
+    }
+    // host wall-clock of the rebuilds (ownership path, exchanges, read-backs, the engines' sort + list: everything between
+    // the last step before and the first step after) and of the blocking read-backs, cumulative; ghost share of domain 0
+    double stat_rebuild_wall_ms = 0.0;
+    int64_t stat_rebuild_calls = 0;
+    void phase_times(double out[8]) override {
+        for (int k = 0; k < 8; k++) out[k] = 0.0;
+        out[0] = stat_rebuild_wall_ms; out[1] = (double)stat_rebuild_calls;
+        double rb = 0.0, nrb = 0.0;
+        std::vector<const emdee_ctx *> seen;
+        for (auto &pd : dom) {
+            if (std::find(seen.begin(), seen.end(), pd->ctx) != seen.end()) continue;
+            seen.push_back(pd->ctx);
+            rb += pd->ctx->readback_ms; nrb += (double)pd->ctx->readbacks;
+        }
+        out[2] = rb; out[3] = nrb;
+        if (!dom.empty() && dom[0]->n_owned + dom[0]->n_ghost > 0) out[4] = (double)dom[0]->n_ghost / (double)(dom[0]->n_owned + dom[0]->n_ghost);
     }
     void rebuild_stats(int64_t out[4]) override {
         out[0] = stat_fast + stat_fallback; out[1] = stat_fallback;

@@ -367,7 +367,10 @@ __global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__
     for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
     if (t < caps.npeers) {
         int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(GhostRow<real>)) - DD_RHDR);
-        hdr[0] = peer_count[t]; hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
+        // hdr[2]: my error word (an atom that left the neighbourhood of its brick) -- every rank neighbours every other one, so
+        // all of them see it in this exchange and fail together, instead of one throwing while the others walk into the next
+        // step's send / receive with a peer that is gone
+        hdr[0] = peer_count[t]; hdr[1] = over; hdr[2] = w_over[DDW_ERR]; hdr[3] = 0;
     }
     // an overflow anywhere: the rebuild will be redone with counts and no row of this one is looked at -- and the send
     // list (ids, bins, codes: sized by the capacities) does not hold what the counts say
@@ -392,17 +395,19 @@ template <typename real>
 __global__ void k_dd_ghost_counts(DdCaps scaps, DdCaps rcaps, const int *__restrict__ peer_count,
                                   const unsigned char *__restrict__ recv, int *__restrict__ w) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int over = w[DDW_OVER], nsend = 0, nghost = 0;
+    int over = w[DDW_OVER], nsend = 0, nghost = 0, err = w[DDW_ERR];
     for (int p = 0; p < scaps.npeers; p++) {
         const int rcap = rcaps.start[p + 1] - rcaps.start[p], scap = scaps.start[p + 1] - scaps.start[p];
         const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
         over |= hdr[1] | (hdr[0] > rcap) | (peer_count[p] > scap);
+        err |= hdr[2];
         w[DDW_GSEND + p] = peer_count[p];
         w[DDW_GRECV + p] = hdr[0];
         nsend += peer_count[p];
         nghost += hdr[0];
     }
     w[DDW_OVER] = over;
+    w[DDW_ERR] = err;                  // mine or a peer's: the same word on every rank
     w[DDW_NSEND] = nsend;
     w[DDW_NGHOST] = nghost;
 }

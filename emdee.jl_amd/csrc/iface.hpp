@@ -64,6 +64,7 @@ struct IDd {
     virtual void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) = 0;
     virtual void stats(int64_t out[4]) = 0;
     virtual void rebuild_stats(int64_t out[4]) = 0;
+    virtual void phase_times(double out[8]) = 0;
     virtual void set_overlap(bool on) = 0;
 };
 

@@ -291,11 +291,23 @@ struct MdImpl : IMd {
         for (auto &t : sys.timers) t.reset();
     }
     void kernel_time(int kernel, double *total_ms, int64_t *launches) override {
-        EMDEE_REQUIRE(kernel >= 0 && kernel < T_COUNT, EMDEE_ERR_INVALID, "kernel id out of range");
+        // ids 0..3: the TimerIds; 4: every fused step launch (interior + boundary halves of a decomposed step together, as
+        // before they had timers of their own); 5: all but the boundary halves; 6: the boundary halves; 7: the halo of a
+        // decomposed step (pack -> exchange -> unpack)
+        EMDEE_REQUIRE(kernel >= 0 && kernel <= 7, EMDEE_ERR_INVALID, "kernel id out of range");
         use_device(sys.ctx);
-        sys.timers[kernel].collect();
-        if (total_ms) *total_ms = sys.timers[kernel].total_ms;
-        if (launches) *launches = sys.timers[kernel].launches;
+        const int ids[8][2] = {{T_FORCE, -1}, {T_KICK_DRIFT, -1}, {T_REBUILD, -1}, {T_KICK, -1}, {T_STEP, T_STEP_BOUNDARY}, {T_STEP, -1},
+                               {T_STEP_BOUNDARY, -1}, {T_HALO, -1}};
+        double ms = 0.0;
+        int64_t n = 0;
+        for (int q = 0; q < 2; q++) {
+            if (ids[kernel][q] < 0) continue;
+            sys.timers[ids[kernel][q]].collect();
+            ms += sys.timers[ids[kernel][q]].total_ms;
+            n += sys.timers[ids[kernel][q]].launches;
+        }
+        if (total_ms) *total_ms = ms;
+        if (launches) *launches = n;
     }
     void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) override {
         sys.set_langevin(gamma, temperature, seed, first_step, sys.lgv_ids);

@@ -15,7 +15,9 @@
 
 namespace emdee {
 
-enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_STEP = 4, T_COUNT = 5 };
+// T_STEP: every fused step launch but the boundary-brick halves of a decomposed step, which go to T_STEP_BOUNDARY (emdee_md_kernel_time(4)
+// reports the two together, 5 and 6 one each); T_HALO: pack -> exchange -> unpack of a decomposed step, on the stream they run on
+enum TimerId { T_FORCE = 0, T_KICK_DRIFT = 1, T_REBUILD = 2, T_KICK = 3, T_STEP = 4, T_STEP_BOUNDARY = 5, T_HALO = 6, T_COUNT = 7 };
 enum PathId { PATH_BRICK = 0, PATH_DIRECT = 1 };
 
 // in-place exclusive scan of int32 data[0..n) (n may exceed one tile: recursive tile sums)
@@ -954,7 +956,7 @@ struct NbSystem {
         if (!brick_active || n_total == 0) return false;
         if (phase != 2 && !noise_ready) prepare_noise(dt);   // phases 1 and 2 are the two halves of one step
         {
-            Timed t(this, T_STEP);
+            Timed t(this, phase == 2 ? T_STEP_BOUNDARY : T_STEP);
             step_c = c; step_dt = dt;
             force_phase = phase;
             step_guard = guard; step_trigger = trigger;

@@ -78,6 +78,14 @@ set_langevin!(dd::DomainDecomposition, gamma, temperature; seed=0, first_step=0)
 set_overlap!(dd::DomainDecomposition, on::Bool) =
     check(ccall((:emdee_dd_set_overlap, libemdee_hip), Int32, (Ptr{Cvoid}, Int32), dd.handle, on ? 1 : 0))
 
+# int32_t emdee_dd_phase_times(emdee_dd *dd, double out[8]);
+# (cumulative host-side times: ms inside rebuilds and their number, ms of blocking read-backs and their number, ghost share)
+function phase_times(dd::DomainDecomposition)
+    out = zeros(Float64, 8)
+    check(ccall((:emdee_dd_phase_times, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Float64}), dd.handle, out))
+    (rebuild_ms = out[1], rebuilds = Int(out[2]), readback_ms = out[3], readbacks = Int(out[4]), ghost_fraction = out[5])
+end
+
 # int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]);
 # (count-free rebuilds, those redone with exact counts, migrant rows per message, ghost rows the messages hold)
 function rebuild_stats(dd::DomainDecomposition)

@@ -8,7 +8,10 @@ from . import _lib
 from .device import check_array, context_for, precision_of
 from .nonbonded import ENERGIES, FORCES, VIRIALS
 
-KERNELS = {"lj_force_nbr": 0, "verlet_kick_drift": 1, "rebuild": 2, "verlet_kick": 3, "lj_force_nbr_fused_step": 4}
+KERNELS = {"lj_force_nbr": 0, "verlet_kick_drift": 1, "rebuild": 2, "verlet_kick": 3, "lj_force_nbr_fused_step": 4,
+           # decomposed steps: the fused launches over interior bricks (or all bricks, in-order form), over boundary bricks, and the
+           # halo (pack -> exchange -> unpack) on the stream it runs on
+           "fused_step_interior": 5, "fused_step_boundary": 6, "halo": 7}
 
 
 class VelocityVerlet:

@@ -310,6 +310,13 @@ int32_t emdee_dd_stats(emdee_dd *dd, int64_t out[4]);
  * capacity was exceeded on some rank, out[2] = migrant rows a message holds per peer, out[3] = ghost rows the messages
  * of local domain 0 hold in all (send side). */
 int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]);
+/* Where the host-side time of this process's decomposition goes, cumulative since emdee_dd_create (take differences
+ * around a timed region): out[0] = wall-clock ms inside rebuilds (ownership path, exchanges, read-backs, the engines'
+ * sort + list), out[1] = rebuilds (the load included), out[2] = wall-clock ms of blocking read-backs of device words,
+ * out[3] = read-backs, out[4] = ghost share n_ghost / (n_owned + n_ghost) of local domain 0 as of now, out[5..7] = 0.
+ * The device-side phases of a step are emdee_md_kernel_time of emdee_dd_engine: 5 = fused step launches over interior
+ * bricks (or all bricks, in-order form), 6 = over boundary bricks, 7 = halo (pack -> exchange -> unpack), 2 = sort + list. */
+int32_t emdee_dd_phase_times(emdee_dd *dd, double out[8]);
 /* How a step meets its halo exchange.  1 (default): interior bricks while the messages travel on a communication stream,
  * boundary bricks on a stream of their own when they have arrived.  0: pack, exchange, unpack and ONE launch over all
  * bricks, in order on the compute stream -- no events, no split launch; cheaper when the messages are short next to the

@@ -4,6 +4,7 @@ torch.distributed.run like the real thing.  Behaviour is chosen by FAKE_RANKS_MO
   fail    without `--dd torch`: exit status 17 at once; with it: print the line
   late    print the line, then never finish (a rank stuck in a final barrier)
   twice   every rank prints a line (a launcher must let one through)
+  crash   rank 0 prints the line, then rank 1 dies with status 9 (a fault after the measurement: teardown, the target-box leg)
 """
 import json
 import os
@@ -33,3 +34,6 @@ if mode == "twice" or rank == 0:
     line()
 if mode == "late":
     time.sleep(3600)
+if mode == "crash" and rank == 1:
+    time.sleep(1.0)
+    os._exit(9)

@@ -98,8 +98,19 @@ def test_a_printed_line_is_never_followed_by_a_second_run():
     """ADVICE r2 (bench.py:92): rank 0 prints the line and then hangs (a final barrier nobody reaches): the launcher stops
     the ranks at the deadline, reports success -- the measurement is out -- and does NOT start the torch driver."""
     r, lines, took = _launch("late", "--deadline", "25", "--retry-min", "1")
-    assert r.returncode == 0 and len(lines) == 1 and "degraded" not in lines[0]
+    assert r.returncode == 0 and len(lines) == 1 and "degraded" not in lines[0] and lines[0]["exit_status"] == 124
     assert "once more" not in r.stderr and took < 25.0
+
+
+def test_a_crash_after_the_line_shows_in_the_line():
+    """ADVICE r3 (bench.py:222): the measurement is complete once its line exists, so the launcher still reports success and
+    starts nothing again -- but the rank group's abnormal end is in the run's records: top-level exit_status != 0 (a normal
+    run carries exit_status 0), and a note on stderr."""
+    r, lines, _ = _launch("crash", "--deadline", "60", "--retry-min", "1")
+    assert r.returncode == 0 and len(lines) == 1 and lines[0]["exit_status"] != 0
+    assert "AFTER its result line" in r.stderr and "once more" not in r.stderr
+    r, lines, _ = _launch("twice", "--deadline", "60")
+    assert lines[0]["exit_status"] == 0
 
 
 def test_only_one_line_reaches_stdout():

@@ -39,6 +39,9 @@ def test_native_decomposition_line_and_target_box():
     t = d["target_box"]
     assert "error" not in t, t
     assert t["atoms"] == 4 * 16 ** 3 and t["steps_per_sec"] > 0 and t["energy_per_atom"]["kinetic"] > 0.5
+    pr = d["per_rank"]["ranks"]                                    # both in-process domains report their phases
+    assert len(pr) == 2 and sum(r["atoms_owned"] for r in pr) == 4 * 12 ** 3
+    assert all(r["force_interior_ms"] > 0 and r["halo_ms"] > 0 and r["ghost_fraction"] > 0.05 for r in pr)
     one = _bench("--cells", "12", "--steps", "8", "--warmup", "4", "--no-cpu-baseline")
     # the decomposed box is the same physical system: same energies per atom after the same number of steps
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
@@ -86,6 +89,15 @@ def test_two_ranks_over_rccl_on_one_gpu():
     t = d["target_box"]
     assert "error" not in t, t
     assert t["atoms"] == 4 * 20 ** 3 and t["steps_per_sec"] > 0
+    # where each rank's step went: both ranks report, interior + boundary launches (or one launch over all
+    # bricks in the in-order form), the halo on its stream, the rebuilds' device and wall-clock time, read-backs, ghost share
+    pr = d["per_rank"]["ranks"]
+    assert [r["rank"] for r in pr] == [0, 1] and sum(r["atoms_owned"] for r in pr) == 4 * 16 ** 3
+    for r in pr:
+        assert 0.05 < r["ghost_fraction"] < 0.8 and r["force_interior_ms"] > 0 and r["halo_ms"] > 0
+        assert (r["force_boundary_ms"] > 0) == (h["chosen"] == "overlapped")
+        assert r["rebuilds"] >= 1 and r["rebuild_wall_ms"] > r["rebuild_device_ms"] > 0 and r["readbacks"] >= r["rebuilds"]
+        assert r["readback_wall_ms"] < d["ms_per_step"] and r["force_interior_ms"] + r["force_boundary_ms"] < d["ms_per_step"]
     # the two trials took 2 x (2 + 2) untimed steps: the undivided run gets them as warm-up
     one = _bench("--cells", "16", "--steps", "8", "--warmup", "12", "--no-cpu-baseline")
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)
