@@ -858,7 +858,12 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         auto row_word = [](int r) constexpr { return OPP ? (r <= 4 ? r : 8 - r) : r / PER; };
         auto row_half = [](int r) constexpr { return OPP ? (r > 4 ? 1 : 0) : r % PER; };
         constexpr int LOG2G = G == 8 ? 3 : 4, KSTEP = STRIDED ? G : 1;
+        // first own atom of this wavefront in a round (a scalar): a wavefront whose eight groups all lie past the brick's last
+        // atom in the last round has nothing to list -- it used to walk the whole round with empty rows (~450 instructions of
+        // bookkeeping: 4 of the 40 wavefront-rounds of a 282-atom brick)
+        const int wave_first = __builtin_amdgcn_readfirstlane((tid / WAVE) * (WAVE / G));
         for (int ob = 0; ob < n_own; ob += NGROUPS) {         // wave-uniform trip count
+            if (ob + wave_first >= n_own) break;
             const int o = ob + gid;
             const bool have = o < n_own;
             // own atom: cell-order slot, tile slot, own cell and "owned" flag, located once while the tile was staged
@@ -995,7 +1000,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 }
                 if (TAIL && (trips & 1)) {
                     const float4 q = cand[(trips - 1) * KSTEP];
-                    if constexpr (!BAND) asm volatile("" : : "v"(q.w));
+                    asm volatile("" : : "v"(q.w));          // (the whole record: a ds_read_b96 costs twice the LDS cycles of a ds_read_b128)
                     float t = dist(q);
                     if constexpr (BAND) {
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_fabsf(t) <= margin_v) != 0, 0))

@@ -136,7 +136,10 @@ def test_neighbor_path_on_reference_fixture(emdee, oracle, dev, lj_sample, golde
         assert w.sum() == pytest.approx(-957.3125855282784, rel=1e-10)
         assert np.abs(f.sum(axis=0)).max() < 1e-9
     else:
-        # fp32 storage: ~1e-5 of the largest value (|W| reaches 50 here), 1e-4 on energies as in the reference
+        # fp32 storage against the FP64 oracle: ~1e-5 of the largest value (|W| reaches 50 here), 1e-4 on energies as in the
+        # reference.  This is the loose, cross-precision bound (1e-4 x max|F|, max|F| = 95 here); the reference's own bound --
+        # 1e-4 ABSOLUTE on forces, energies and virials between two Float32 implementations -- is held against the FP32 oracle
+        # in tests/test_gpu_parity2.py::test_fp32_reference_bound_per_quantity
         assert np.abs(f - f0).max() < 1e-4 * max(1.0, np.abs(f0).max())
         assert np.abs(e - e0).max() < 1e-4 and np.abs(w - w0).max() < 1e-5 * np.abs(w0).max()
     st = tiles.stats()
@@ -600,10 +603,11 @@ def test_long_rows_binary_mixture_rc35(emdee, oracle, dev):
     assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
 
 
-def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev):
+def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev, capfd, monkeypatch):
     """BASELINE configs[4] at the size it is quoted on: 10,061,824 atoms, two species (Lorentz-Berthelot through the LJAtom
-    encoding, src/lennard_jones.jl:13-18,29-30), rc = 3.5 sigma -- the general-species kernels with 184-entry rows, 135 KB
-    tiles.  No CPU oracle finishes this box in seconds; asserted are the size-independent properties: counted in-cutoff
+    encoding, src/lennard_jones.jl:13-18,29-30), rc = 3.5 sigma -- stepped by the TYPED two-species kernels (csrc/typed.hpp:
+    rows of two segments, 184 entries, coordinate-plane tiles; asserted below from the plan the library prints).  No CPU
+    oracle finishes this box in seconds; asserted are the size-independent properties: counted in-cutoff
     pairs against nbar(3.5) = 143.68, Newton's third law (total force), momentum and energy conservation over the bench's
     own step loop, rows inside their capacity, displacement-triggered rebuilds."""
     E = emdee
@@ -615,7 +619,11 @@ def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev):
     eps, sigma = syn.mixture_parameters(types)
     assert 0.2 < types.mean() < 0.8                                       # really two species
     atoms = E.lennard_jones_atoms(eps, sigma)
+    monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+    capfd.readouterr()
     md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(3.5, 3.0), E.cu(atoms, dev), skin=0.3)
+    torch.cuda.synchronize()
+    assert "typed kernels on" in capfd.readouterr().err               # the kernels that step THIS box are the typed ones
     del pos, vel
     ep0, ek0, _ = md.totals()
     pairs = md.count_pairs()
@@ -644,6 +652,7 @@ def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev):
     small.close()
     v = md.state(positions=False, forces=False)["velocities"]
     assert v.sum(dim=0).abs().max().item() < 1e-9 * N                      # total momentum (starts at rounding level)
+    assert "typed kernels off" not in capfd.readouterr().err           # ... and stayed so through every re-plan of the run
     st = md.nbr_stats()
     assert st["builds"] >= 4 and st["max_count"] <= st["capacity"] and st["listed"] / N > 170
     assert abs(md.count_pairs() / (0.5 * N) - 143.68) < 4.0               # melting towards the uniform fluid's 143.68
