@@ -481,7 +481,7 @@ constexpr int BUILD2_FIELD = 16;                      // bits per tile row in a 
 // G = lanes that share one atom HERE; GL = lanes per atom of the force kernels, which fixes the lane-major row
 // layout (row_position<GL>) -- the two need not agree.
 template <typename real, class Shape, int THREADS, int G, int ALG = 1, int GL = G>
-__global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_build(BrickArgs<real> a) {   // <= 80 VGPRs: three 512-thread workgroups per CU
+__global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_build(BrickArgs<real> a) {   // <= 80 VGPRs: three 512-thread (or two 768-thread) workgroups per CU
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         // the loop needs no per-lane exit bookkeeping on the execution mask; the hit bit is shifted in by the carry
         // input of one add (v_cmp -> vcc, v_addc: bits = 2 bits + hit); and the squared distance is accumulated
         // starting from -r_list^2, so "surely inside" and "inside the rounding band" are compares against +-margin.
-        static_assert(G == 8 || G == 16, "two-phase build: 8 or 16 lanes per atom");
+        static_assert(G == 4 || G == 8 || G == 16, "two-phase build: 4, 8 or 16 lanes per atom");
         // ALG 3: two 16-bit fields per word (a lane's chunk of a tile row holds <= 16 candidates); ALG 5: one 32-bit field per
         // word, for long cutoffs / dense boxes (rc = 3.5 sigma: 132 candidates per row, 17 per lane)
         constexpr int FIELD = ALG % 10 == 3 ? BUILD2_FIELD : 32, PER = 32 / FIELD;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
         constexpr bool OPP = EMDEE_BUILD_PAIR_OPPOSITE != 0 && PER == 2;
         auto row_word = [](int r) constexpr { return OPP ? (r <= 4 ? r : 8 - r) : r / PER; };
         auto row_half = [](int r) constexpr { return OPP ? (r > 4 ? 1 : 0) : r % PER; };
-        constexpr int LOG2G = G == 8 ? 3 : 4, KSTEP = STRIDED ? G : 1;
+        constexpr int LOG2G = G == 4 ? 2 : (G == 8 ? 3 : 4), KSTEP = STRIDED ? G : 1;
         // first own atom of this wavefront in a round (a scalar): a wavefront whose eight groups all lie past the brick's last
         // atom in the last round has nothing to list -- it used to walk the whole round with empty rows (~450 instructions of
         // bookkeeping: 4 of the 40 wavefront-rounds of a 282-atom brick)
@@ -880,14 +880,21 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
             int trips_of[NROWS];
             if constexpr (RT) {
                 rv_next = rt_get(rt, 0);
-                // chunk length of row gl (G = 8: rows 0..7 in the lanes, row 8 apart; G = 16: lanes 0..8 hold all nine)
-                int cv = (int)((unsigned)(rt_get(rt, min(gl, NROWS - 1)).y + G - 1) / (unsigned)G);
-                int c8 = (int)((unsigned)(rt_get(rt, NROWS - 1).y + G - 1) / (unsigned)G);
-                if constexpr (G == 8) {
-                    cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
-                    c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
+                // chunk length of row gl (G = 8: rows 0..7 in the lanes, row 8 apart; G = 16: lanes 0..8 hold all nine; G = 4: rows
+                // 0..3 in cv, 4..7 in cw, row 8 apart)
+                auto chunk_of = [&](int r) { return (int)((unsigned)(rt_get(rt, r).y + G - 1) / (unsigned)G); };
+                int cv = chunk_of(min(gl, NROWS - 1));
+                int cw = G == 4 ? chunk_of(4 + gl) : 0;
+                int c8 = chunk_of(NROWS - 1);
+                // across the groups of a 16-lane row with row rotations, across the four rows with the gfx950 row / half swaps
+                // (no LDS, no address registers)
+                auto ror4 = [](int v) { return max(v, __builtin_amdgcn_update_dpp(0, v, 0x124 /* row_ror:4 */, 0xf, 0xf, true)); };
+                auto ror8 = [](int v) { return max(v, __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, true)); };
+                if constexpr (G == 4) { cv = ror4(cv); cw = ror4(cw); c8 = ror4(c8); }
+                if constexpr (G <= 8) {
+                    cv = ror8(cv); c8 = ror8(c8);
+                    if constexpr (G == 4) cw = ror8(cw);
                 }
-                // across the four 16-lane rows with the gfx950 row / half swaps (no LDS, no address registers)
                 auto rows_max = [](int v) {
                     auto q = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
                     v = max((int)q[0], (int)q[1]);
@@ -895,11 +902,18 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                     return max((int)q[0], (int)q[1]);
                 };
                 cv = rows_max(cv);
-                if constexpr (G == 8) c8 = rows_max(c8);
+                if constexpr (G <= 8) c8 = rows_max(c8);
+                if constexpr (G == 4) cw = rows_max(cw);
 #pragma unroll
                 for (int r = 0; r < NROWS; r++) {
-                    const int m = (G == 8 && r == NROWS - 1) ? __builtin_amdgcn_readlane(c8, 0) : __builtin_amdgcn_readlane(cv, r);
+                    int m;
+                    if (G <= 8 && r == NROWS - 1) m = __builtin_amdgcn_readlane(c8, 0);
+                    else if (G == 4 && r >= 4) m = __builtin_amdgcn_readlane(cw, r - 4);
+                    else m = __builtin_amdgcn_readlane(cv, r);
                     trips_of[r] = TAIL ? m : ((m + UNR - 1) & ~(UNR - 1));
+                    // (a lane's share of a tile row must fit its bit field: the host picked the field from the widest 3-cell run,
+                    // which the x sub-bins undercut -- and with 4 lanes per atom only THEY keep a row within 16 x 4 slots)
+                    if (FIELD < 32 && m > FIELD && lane == 0) atomicMax(&a.flags[4], m);
                 }
             }
 #pragma unroll
@@ -1035,8 +1049,10 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_brick_bui
                 incl += gl >= 1 ? t : 0;
                 t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR2, 0xf, 0xf, true);
                 incl += gl >= 2 ? t : 0;
-                t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR4, 0xf, 0xf, true);
-                incl += gl >= 4 ? t : 0;
+                if (G >= 8) {
+                    t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR4, 0xf, 0xf, true);
+                    incl += gl >= 4 ? t : 0;
+                }
                 if (G == 16) {
                     t = __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_SHR8, 0xf, 0xf, true);
                     incl += gl >= 8 ? t : 0;

@@ -123,6 +123,17 @@ struct NbSystem {
     bool tbuild_enabled = std::getenv("EMDEE_TBUILD") != nullptr && std::atoi(std::getenv("EMDEE_TBUILD")) != 0 &&
                           std::getenv("EMDEE_BUILD_ALG") == nullptr && std::getenv("EMDEE_BUILD_NEARFAR") == nullptr;
     bool tbuild_blocked = false;
+    // Four lanes per atom in the round-robin build (round 4; EMDEE_BUILD4=1 switches it on): 16 atoms per wavefront share what
+    // is paid once per atom and wavefront-round (row bookkeeping, trip counts, prefix: 400 of ~960 instructions per atom and lane
+    // at 8 lanes), the emission loops run on twice the hits per lane (less imbalance), and twice the row buffers fit because the
+    // workgroup is 768 threads, two per CU: still six waves per SIMD.  Measured: 1.927 ms per launch against 1.90-1.93 with 8
+    // lanes and 512 threads -- a quarter fewer vector instructions and no gain, i.e. the kernel is as much bound by its LDS reads
+    // (one ds_read_b128 per candidate and lane: 5.7 KB per atom, SQ_LDS_IDX_ACTIVE 55-65 % of the kernel) as by issue, and those
+    // do not change.  Off by default.  A lane's share of a tile row must fit a 16-bit field (64 slots per row): the x sub-bins
+    // see to that in a fluid; the kernel reports a wider row in flags[4] and the state goes on with 8 lanes.
+    bool build4_enabled = std::getenv("EMDEE_BUILD4") != nullptr && std::atoi(std::getenv("EMDEE_BUILD4")) != 0;
+    bool build4_blocked = false;
+    static constexpr int B4_THREADS = 768, B4_G = 4;
     static constexpr int TB_NPAIR = 5;    // 640 candidates per own cell (27 cells of 17.6 atoms at rho* = 0.8, r_list = 2.8: 475)
     template <class V>
     bool tbuild_active() const { return tbuild_enabled && !tbuild_blocked && !typed_active && std::is_same<V, BrickVariant<0>>::value; }
@@ -717,7 +728,7 @@ struct NbSystem {
         }
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 4 * sizeof(int), stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 5 * sizeof(int), stream()));
             if (brick_active) {
                 nbr16.ensure((size_t)std::max(n, 1) * stride);
                 with_brick_variant(variant, [&](auto v) {
@@ -776,6 +787,18 @@ struct NbSystem {
                             const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !std::getenv("EMDEE_BUILD_CHUNKED") &&
                                                     (V::G == 4 || std::getenv("EMDEE_BUILD_STRIDED") != nullptr);
                             if (build_alg == 3 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 13, V::G>;
+                            if constexpr (std::is_same<V, BrickVariant<0>>::value) {
+                                if (build_alg == 3 && strided_ok && nsub == 4 && build4_enabled && !build4_blocked && near_far_scale() <= 0.0) {
+                                    auto k4 = k_brick_build<real, typename V::Shape, B4_THREADS, B4_G, 13, V::G>;
+                                    const size_t lds4 = brick_build_lds_bytes<typename V::Shape, B4_THREADS>(tile_cap, own_cap, stride, B4_G, nsub);
+                                    if (lds4 <= LDS_LIMIT) {
+                                        lds_build_bytes = lds4;
+                                        allow_big_lds(k4, lds4);
+                                        hipLaunchKernelGGL(k4, dim3(bgrid.per_xcd * NXCD), dim3(B4_THREADS), lds4, stream(), brick_args());
+                                        return;
+                                    }
+                                }
+                            }
                             // ... and near entries first (brick.hpp ALG 23), when the skin leaves room for a near radius
                             if (build_alg == 3 && strided_ok && near_far_scale() > 0.0) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 23, V::G>;
                             if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
@@ -802,6 +825,12 @@ struct NbSystem {
                 plan_valid = false;
                 btab_valid = false;
                 make_plan();
+                continue;
+            }
+            if (brick_active && ctx->host_flags[4] != 0 && !build4_blocked) {
+                // a tile row wider than 4 lanes x 16-bit fields take: this state goes on with 8 lanes per atom in the build
+                build4_blocked = true;
+                if (std::getenv("EMDEE_DEBUG_PLAN")) std::fprintf(stderr, "emdee plan: a tile row needs %d trips of 4 lanes (> 16): the build goes on with 8 lanes per atom\n", ctx->host_flags[4]);
                 continue;
             }
             if (brick_active && ctx->host_flags[3] != 0 && !tbuild_blocked) {
@@ -868,6 +897,7 @@ struct NbSystem {
         species.n = 1;
         typed_blocked = false;
         tbuild_blocked = false;
+        build4_blocked = false;
         if (uniform_known >= 0 && n_total > 0) {
             uniform_atoms = uniform_known == 1;
             // (decomposed runs: the two species every domain agreed on at the first load, emdee_dd_load)
