@@ -993,6 +993,15 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
                     float t[UNR];
 #pragma unroll
                     for (int u = 0; u < UNR; u++) q[u] = cand[(k + u) * KSTEP];
+#ifdef EMDEE_BUILD_ABLATE      // 8: half the candidate reads (the second candidate of a trip is the first again); 16: every read twice
+                    if (EMDEE_BUILD_ABLATE & 8) { q[1] = q[0]; asm volatile("" : "+v"(q[1].x)); }
+                    if (EMDEE_BUILD_ABLATE & 16) {
+                        float4 extra = cand[(k + 1) * KSTEP + 1];
+                        asm volatile("" : : "v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                        extra = cand[k * KSTEP + 1];
+                        asm volatile("" : : "v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                    }
+#endif
                     // (keeps the whole 16-byte records alive: a ds_read_b96 costs 8 LDS cycles per wavefront, a ds_read_b128 4)
                     if constexpr (!BAND) {
 #pragma unroll
