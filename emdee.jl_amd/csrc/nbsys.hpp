@@ -127,9 +127,9 @@ struct NbSystem {
     // is paid once per atom and wavefront-round (row bookkeeping, trip counts, prefix: 400 of ~960 instructions per atom and lane
     // at 8 lanes), the emission loops run on twice the hits per lane (less imbalance), and twice the row buffers fit because the
     // workgroup is 768 threads, two per CU: still six waves per SIMD.  Measured: 1.927 ms per launch against 1.90-1.93 with 8
-    // lanes and 512 threads -- a quarter fewer vector instructions and no gain, i.e. the kernel is as much bound by its LDS reads
-    // (one ds_read_b128 per candidate and lane: 5.7 KB per atom, SQ_LDS_IDX_ACTIVE 55-65 % of the kernel) as by issue, and those
-    // do not change.  Off by default.  A lane's share of a tile row must fit a 16-bit field (64 slots per row): the x sub-bins
+    // lanes and 512 threads -- 11 % fewer vector instructions (SQ counters) and no gain: in both forms the waves sit at
+    // s_waitcnt for 42-48 % of their lifetime, and doubling the candidate LDS reads costs only 12 % (profiles/r04/
+    // tbuild_transposed_build.txt): dependent-chain latency, which the dealing does not change.  Off by default.  A lane's share of a tile row must fit a 16-bit field (64 slots per row): the x sub-bins
     // see to that in a fluid; the kernel reports a wider row in flags[4] and the state goes on with 8 lanes.
     bool build4_enabled = std::getenv("EMDEE_BUILD4") != nullptr && std::atoi(std::getenv("EMDEE_BUILD4")) != 0;
     bool build4_blocked = false;
