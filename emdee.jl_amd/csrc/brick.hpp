@@ -492,7 +492,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     // x sub-bins (the two-phase builds that take their candidate rows from the row table): rows per own cell AND sub-bin
-    constexpr bool SUBOK = ALG == 3 || ALG == 5 || ALG == 13 || ALG == 15;
+    constexpr bool SUBOK = ALG == 3 || ALG == 5 || ALG == 13 || ALG == 15 || ALG == 23;
     const int NSUB = (SUBOK && a.nsub == 4 && a.bsub != nullptr) ? 4 : 1;
     // (one word per row: first slot | slots << 16 -- a tile holds < 2^16 slots; the build's LDS decides whether a CU takes
     // three workgroups.  The sub-bin boundaries of the tile cells are only needed until the row table is written: they
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             const float4 qi = tile[ti];
             unsigned short *row = a.nbr + (size_t)p * a.stride;
             for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
-            const unsigned *rt = rtab + (act ? oc : Shape::NOC) * 9;
+            const unsigned *rt = rtab + (act ? oc * NSUB + ((info.y >> 17) & 3) : Shape::NOC * NSUB) * 9;   // (x sub-bins: as ALG 13)
             int trips_of[NROWS];
             {   // wave-uniform trip counts of the nine rows from one reduction (as ALG 13)
                 int cv = (int)((unsigned)(rt_get(rt, min(gl, NROWS - 1)).y + G - 1) / (unsigned)G);
@@ -757,28 +757,40 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             const int totalN = __shfl(inclN, lane | (G - 1));
             unsigned short *epN = rowbuf + (unsigned)(inclN - mineN), *epF = rowbuf + (unsigned)(totalN + inclF - mineF);
             unsigned short *const ep_last = rowbuf + (ustride - 1u);
-            rv_next = rt_get(rt, 0);
+            // Round 4: TEN emission loops instead of eighteen.  The listed / near masks of a row have their digits at the EVEN bit
+            // positions (digit j at bit 2 j), so the masks of two rows fit one word, the second shifted to the odd positions;
+            // the pairs are OPPOSITE rows, (dy, dz) with (-dy, -dz) -- their hits add up to nearly the same number for every atom,
+            // and a loop runs as long as the busiest of 64 lanes -- and row 4 stays alone.  Bit b of a word: row A (b even) or B
+            // (b odd), digit b >> 1 = tile slot c0 + gl + (trips - 1 - j) G.
+            const int negstep = -(1 << (kshift - 1));                 // slot step per unit of (b & ~1), as a list entry
 #pragma unroll
-            for (int r = 0; r < NROWS; r++) {
-                const int c0 = rv_next.x;
-                if (r + 1 < NROWS) rv_next = rt_get(rt, r + 1);
-                // digit j (bit 2 j of the masks below) is tile slot c0 + gl + (trips - 1 - j) G
-                int base = (c0 + gl + (trips_of[r] - 1) * G) << a.idx_shift;
-                asm volatile("" : "+v"(base));
-                const unsigned H = (D[r] >> 1) & 0x55555555u;
-                unsigned WN = H & D[r], WF = H & ~D[r];
+            for (int w = 0; w < 5; w++) {
+                const int rA = w, rB = 8 - w;
+                const unsigned HA = (D[rA] >> 1) & 0x55555555u;
+                unsigned WN = HA & D[rA], WF = HA & ~D[rA];
+                int baseA = (rt_get(rt, rA).x + gl + (trips_of[rA] - 1) * G) << a.idx_shift, dBA = 0;
+                if (w < 4) {
+                    const unsigned HB = (D[rB] >> 1) & 0x55555555u;
+                    WN |= (HB & D[rB]) << 1;
+                    WF |= (HB & ~D[rB]) << 1;
+                    dBA = ((rt_get(rt, rB).x + gl + (trips_of[rB] - 1) * G) << a.idx_shift) - baseA;
+                }
+                asm volatile("" : "+v"(baseA), "+v"(dBA));
+                auto entry = [&](int b) {                              // two multiply-adds (24-bit): base of the row, minus the digit's step
+                    return baseA + __mul24(b & 1, dBA) + __mul24(b & ~1, negstep);
+                };
                 while (WN) {
-                    const int b = __ffs((int)WN) - 1;                 // = 2 j
+                    const int b = __ffs((int)WN) - 1;
                     WN &= WN - 1;
                     asm volatile("" : "+v"(WN));
-                    *(epN < ep_last ? epN : ep_last) = (unsigned short)(base - (b << (kshift - 1)));
+                    *(epN < ep_last ? epN : ep_last) = (unsigned short)entry(b);
                     epN++;
                 }
                 while (WF) {
                     const int b = __ffs((int)WF) - 1;
                     WF &= WF - 1;
                     asm volatile("" : "+v"(WF));
-                    *(epF < ep_last ? epF : ep_last) = (unsigned short)(base - (b << (kshift - 1)));
+                    *(epF < ep_last ? epF : ep_last) = (unsigned short)entry(b);
                     epF++;
                 }
             }
