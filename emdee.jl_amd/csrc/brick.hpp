@@ -762,7 +762,6 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             // the pairs are OPPOSITE rows, (dy, dz) with (-dy, -dz) -- their hits add up to nearly the same number for every atom,
             // and a loop runs as long as the busiest of 64 lanes -- and row 4 stays alone.  Bit b of a word: row A (b even) or B
             // (b odd), digit b >> 1 = tile slot c0 + gl + (trips - 1 - j) G.
-            const int negstep = -(1 << (kshift - 1));                 // slot step per unit of (b & ~1), as a list entry
 #pragma unroll
             for (int w = 0; w < 5; w++) {
                 const int rA = w, rB = 8 - w;
@@ -776,8 +775,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
                     dBA = ((rt_get(rt, rB).x + gl + (trips_of[rB] - 1) * G) << a.idx_shift) - baseA;
                 }
                 asm volatile("" : "+v"(baseA), "+v"(dBA));
-                auto entry = [&](int b) {                              // two multiply-adds (24-bit): base of the row, minus the digit's step
-                    return baseA + __mul24(b & 1, dBA) + __mul24(b & ~1, negstep);
+                auto entry = [&](int b) {                              // base of the row the bit belongs to, minus the digit's step
+                    // (a shift, not a multiply: v_mul_lo_u32 is a quarter-rate instruction, and the compiler picks it for a product)
+                    return baseA + ((b & 1) ? dBA : 0) - ((b >> 1) << kshift);
                 };
                 while (WN) {
                     const int b = __ffs((int)WN) - 1;
