@@ -775,6 +775,10 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
                     dBA = ((rt_get(rt, rB).x + gl + (trips_of[rB] - 1) * G) << a.idx_shift) - baseA;
                 }
                 asm volatile("" : "+v"(baseA), "+v"(dBA));
+#ifdef EMDEE_BUILD_ABLATE      // timing experiments only (the lists are wrong): 2 no emission
+                if (EMDEE_BUILD_ABLATE & 2) { WN = 0; WF = 0; }
+                if (EMDEE_BUILD_ABLATE & 32) { WN |= WF; WF = 0; }     // 32: one class (all hits through the near loops)
+#endif
                 auto entry = [&](int b) {                              // base of the row the bit belongs to, minus the digit's step
                     // (a shift, not a multiply: v_mul_lo_u32 is a quarter-rate instruction, and the compiler picks it for a product)
                     return baseA + ((b & 1) ? dBA : 0) - ((b >> 1) << kshift);
