@@ -185,16 +185,35 @@ struct RecSpecies<float> {
 // distinct LJAtom values of a box, at most MAX_SPECIES: tab[0..3] = keys in order of arrival (EMPTY = all ones),
 // tab[4] != 0 if there are more.  Almost every thread finds its key with device-scope loads; the atomics are for the
 // first few arrivals.
+// (Round 4: ONE look-up per distinct key of a wavefront, by the first lane that holds it -- every thread looking at the hot words
+// itself was 10^7 device-scope loads of four addresses: 2-6 ms at every load of a 10^7-atom state, more than its whole sort.)
 static __global__ void k_species_collect(int n, const emdee_lj_atom *__restrict__ atoms, unsigned long long *__restrict__ tab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long mine = species_key(atoms[i].half_sigma, atoms[i].twice_sqrt_eps), EMPTY = ~0ull;
-    for (int q = 0; q < MAX_SPECIES; q++) {
-        unsigned long long cur = __hip_atomic_load(&tab[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY) cur = atomicCAS(&tab[q], EMPTY, mine);
-        if (cur == EMPTY || cur == mine) return;
+    const unsigned long long EMPTY = ~0ull;
+    unsigned long long mine = EMPTY;
+    bool pending = i < n;
+    if (pending) mine = species_key(atoms[i].half_sigma, atoms[i].twice_sqrt_eps);
+    const int lane = lane_id();
+    for (int round = 0; round <= MAX_SPECIES; round++) {       // at most MAX_SPECIES + 1 distinct keys matter: one more is "too many"
+        const unsigned long long left = __ballot(pending);
+        if (left == 0) return;
+        const int leader = __ffsll((long long)left) - 1;
+        const unsigned lo = __shfl((unsigned)mine, leader), hi = __shfl((unsigned)(mine >> 32), leader);
+        const unsigned long long key = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        if (pending && mine == key) {
+            pending = false;
+            if (lane == leader) {
+                bool found = false;
+                for (int q = 0; q < MAX_SPECIES && !found; q++) {
+                    unsigned long long cur = __hip_atomic_load(&tab[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == EMPTY) cur = atomicCAS(&tab[q], EMPTY, key);
+                    found = cur == EMPTY || cur == key;
+                }
+                if (!found) tab[MAX_SPECIES] = 1;
+            }
+        }
     }
-    tab[MAX_SPECIES] = 1;
+    if (__ballot(pending) != 0 && lane == 0) tab[MAX_SPECIES] = 1;   // a wavefront with more distinct keys than the table holds
 }
 // cstart[c] = first slot of cell c, from the per-(cell, species) starts of a typed sort
 static __global__ void k_cell_starts(int ncell, int nt, const int *__restrict__ tstart, int *__restrict__ cstart) {
