@@ -507,6 +507,9 @@ __global__ void k_refresh_check(int n, size_t pitch, GridP<real> g, const int *_
     if (__float_as_int(a.half_sigma) != __float_as_int(first.half_sigma) ||
         __float_as_int(a.twice_sqrt_eps) != __float_as_int(first.twice_sqrt_eps))
         flags[5] = 1;
+    // the first LJAtom itself rides along (flags[14], [15]): the host needs it for the single-species constants, and one
+    // posted read-back of the words is cheaper than two copies and a synchronisation
+    if (p == 0) { flags[14] = __float_as_int(first.half_sigma); flags[15] = __float_as_int(first.twice_sqrt_eps); }
 }
 
 // Operator path: has any atom moved more than sqrt(thr2) (minimum image) since the build?
