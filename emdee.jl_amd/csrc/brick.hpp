@@ -97,7 +97,8 @@ __device__ __forceinline__ void tile_load<float>(const Rec<float> *tile, const f
 
 template <typename real>
 struct BrickArgs {
-    int n, n_owned;
+    int n, n_owned;            // slots in use; ids below n_owned are owned atoms, the others ghosts (ids may have gaps)
+    int any_ghosts;
     const Rec<real> *rec;
     const float *te;
     const int *perm;
@@ -342,7 +343,7 @@ __device__ __forceinline__ bool brick_setup(const BrickArgs<real> &a, const Bric
         // but a sliver of them) takes no part in the own-atom loops of the build and force kernels -- ghosts own no row,
         // receive no force and are not integrated, but as own atoms they occupied one lane group each: 16 % of the atoms
         // of a rank of the 8-GPU 10^7-atom run.  Marked with bit 8 of the cell's shift word (part of the stored image).
-        if (COMPUTE && a.n_owned < a.n && valid && my_cnt > 0 && tx >= 1 && tx <= BX && ty >= 1 && ty <= BY && tz >= 1 && tz <= BZ) {
+        if (COMPUTE && a.any_ghosts && valid && my_cnt > 0 && tx >= 1 && tx <= BX && ty >= 1 && ty <= BY && tz >= 1 && tz <= BZ) {
             int owned = 0;
             for (int k = 0; k < my_cnt; k++) owned |= (a.perm[gb + k] < a.n_owned) ? 1 : 0;
             if (!owned) sh |= 256;
@@ -1614,7 +1615,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 // counts[i] entries at out[i * capacity ...], in list order.  One workgroup per brick, like the force kernels.
 template <typename real, class Shape, int THREADS, int G>
 __global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int *__restrict__ counts, int *__restrict__ out,
-                                                          int capacity) {
+                                                          int capacity, const int *__restrict__ cmap = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     BrickTables<Shape, THREADS> T;
     T.carve(s_dyn);
@@ -1623,8 +1624,8 @@ __global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int
     for (int o = threadIdx.x; o < n_own; o += THREADS) {
         int ti, p;
         brick_locate(T, o, ti, p);
-        const int i = a.perm[p];
-        if (i >= a.n_owned) continue;
+        if (a.perm[p] >= a.n_owned) continue;
+        const int i = cmap ? cmap[a.perm[p]] : a.perm[p];
         const int m = a.cnt[p];
         counts[i] = m;
         const unsigned short *row = a.nbr + (size_t)p * a.stride;
@@ -1635,7 +1636,8 @@ __global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int
                 const int mid = (lo + hi) >> 1;
                 if (T.off[mid] <= sl) lo = mid; else hi = mid;
             }
-            out[(size_t)i * capacity + e] = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+            const int j = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+            out[(size_t)i * capacity + e] = cmap ? cmap[j] : j;
         }
     }
 }

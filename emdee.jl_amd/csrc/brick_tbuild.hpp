@@ -79,7 +79,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? EMDEE_TB_WAVES : 4)) voi
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
     // decomposed runs: ghosts own no row (one byte per own atom, in the table's own-atom area)
-    const bool all_owned = a.n_owned >= a.n;
+    const bool all_owned = !a.any_ghosts;
     unsigned char *ownflag = reinterpret_cast<unsigned char *>(T.oinfo);
     if (!all_owned) {
         for (int o = tid; o < n_own; o += THREADS) {

@@ -181,6 +181,35 @@ struct DevBuf {
 
 static inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 
+// An engine that runs on a stream of the library's own (the domains of an in-process decomposition) fills arrays the CALLER
+// handed in -- emdee_dd_get_state, emdee_md_get_state / emdee_md_nbr_list on a domain's engine.  The caller's context
+// stream is where the caller orders its own work on those arrays (an allocator may have recycled the block from work that
+// is still queued there), so the engine's stream first waits for what that stream holds now, and that stream then waits for
+// what the engine writes: two event hops, no device-wide synchronisation, and the results are ordered on the caller's
+// stream exactly as the results of every other call are.  (Round 4 fenced in the Python binding with a device
+// synchronisation; a C or Julia caller of the same entry points had the same race.)  No-op when the two are one stream.
+struct FenceOut {
+    hipStream_t caller, engine;
+    bool live;
+    FenceOut(const emdee_ctx *caller_ctx, hipStream_t engine_stream)
+        : caller(caller_ctx ? caller_ctx->stream : nullptr), engine(engine_stream), live(caller_ctx != nullptr && caller_ctx->stream != engine_stream) {
+        if (live) hop(caller, engine);
+    }
+    ~FenceOut() {
+        if (live) {
+            try { hop(engine, caller); } catch (...) {}
+        }
+    }
+    static void hop(hipStream_t from, hipStream_t to) {
+        hipEvent_t ev;
+        EMDEE_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, from);
+        if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+        (void)hipEventDestroy(ev);                   // (released once the record has completed)
+        EMDEE_HIP_CHECK(e);
+    }
+};
+
 // ------------------------------------------------------------------------------------ small blocking read-backs
 // A rebuild decision, the build's overflow words, the counts of a migration: a few words the host must see before it can
 // queue the next kernel.  hipMemcpyAsync + hipStreamSynchronize leaves 16 us of empty queue behind the producing kernel
@@ -195,18 +224,22 @@ static inline void host_words_alloc(emdee_ctx *ctx) {
     ctx->post_seq = 0;
 }
 
-static __global__ void k_post_words(const int *__restrict__ src, int n, volatile int *dst, volatile int *stamp, int seq) {
+static __global__ void k_post_words(const int *__restrict__ src, int n, volatile int *dst, volatile int *stamp, int seq,
+                                    const int *__restrict__ src2 = nullptr, int n2 = 0) {
     const int t = threadIdx.x;
     if (t < n) dst[t] = src[t];
+    else if (t < n + n2) dst[t] = src2[t - n];
     __threadfence_system();
     __syncthreads();
     if (t == 0) *stamp = seq;
 }
 
 // n <= POST_MAX words of device memory, as they are when the work queued on s so far has run -> out (host); blocking
-static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev, int n, int32_t *out) {
-    EMDEE_REQUIRE(n >= 0 && n <= POST_MAX, EMDEE_ERR_INVALID, "read_back_words: %d words", n);
-    if (n == 0) return;
+// (dev2 / n2 / out2, optional: a second range that rides along -- the words of a decomposed rebuild with the build's)
+static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev, int n, int32_t *out, const int *dev2 = nullptr,
+                                   int n2 = 0, int32_t *out2 = nullptr) {
+    EMDEE_REQUIRE(n >= 0 && n2 >= 0 && n + n2 <= POST_MAX, EMDEE_ERR_INVALID, "read_back_words: %d words", n + n2);
+    if (n + n2 == 0) return;
     const auto t_begin = std::chrono::steady_clock::now();
     struct Clock {
         emdee_ctx *c;
@@ -217,13 +250,14 @@ static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev
     // (EMDEE_READBACK is looked at per call, not per context: a process may hold one context for its whole life)
     const char *form = std::getenv("EMDEE_READBACK");
     if ((form != nullptr && form[0] == 'c') || ctx->post_dev == nullptr) {
-        EMDEE_HIP_CHECK(hipMemcpyAsync(data, dev, n * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (n > 0) EMDEE_HIP_CHECK(hipMemcpyAsync(data, dev, n * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (n2 > 0) EMDEE_HIP_CHECK(hipMemcpyAsync(data + n, dev2, n2 * sizeof(int), hipMemcpyDeviceToHost, s));
         EMDEE_HIP_CHECK(hipStreamSynchronize(s));
     } else {
         if (++ctx->post_seq == 0) ++ctx->post_seq;                         // never 0 (the buffer's initial contents)
         const int seq = (int)ctx->post_seq;
         hipLaunchKernelGGL(k_post_words, dim3(1), dim3(POST_MAX), 0, s, dev, n, (volatile int *)(ctx->post_dev + POST_DATA),
-                           (volatile int *)(ctx->post_dev + POST_STAMP), seq);
+                           (volatile int *)(ctx->post_dev + POST_STAMP), seq, dev2, n2);
         volatile int32_t *stamp = ctx->host_flags + POST_STAMP;
         for (unsigned spins = 1; *stamp != seq; spins++) {
             __builtin_ia32_pause();                                        // (the sibling hyper-thread may be another rank's host thread)
@@ -247,6 +281,7 @@ static inline void read_back_words(emdee_ctx *ctx, hipStream_t s, const int *dev
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     for (int k = 0; k < n; k++) out[k] = ((volatile int32_t *)data)[k];
+    for (int k = 0; k < n2; k++) out2[k] = ((volatile int32_t *)data)[n + k];
 }
 
 // HIP-event pair pool for per-kernel device timing on the context's stream (bench.py's

@@ -208,8 +208,9 @@ struct Domain {
     DevBuf<real> x, x2, v, v2, f;
     DevBuf<emdee_lj_atom> at, at2;
     DevBuf<long long> gid, gid2;
-    DevBuf<unsigned> mask;
-    DevBuf<int> counts, ids, bins, codes, small;   // small: bin_start[33] | cnt_send[27] | cnt_recv[27] | err[1]
+    DevBuf<unsigned> mask, gmask;
+    DevBuf<unsigned char> keep;                    // rebuild in the engine's order: slots that make it into the new state
+    DevBuf<int> counts, counts2, ids, bins, codes, small, small2;   // small: bin_start[33] | cnt_send[27] | cnt_recv[27] | err[1]
     DevBuf<unsigned char> sendbuf, recvbuf;
     DevBuf<int> words;
     DevBuf<double> red;
@@ -323,6 +324,8 @@ struct DdImpl : IDd {
             EMDEE_HIP_CHECK(hipEventCreateWithFlags(&d->ev_bnd, hipEventDisableTiming));
             const int32_t per[3] = {d->geo.periodic[0], d->geo.periodic[1], d->geo.periodic[2]};
             d->md = std::make_unique<MdImpl<real>>(d->ctx, d->geo.local_lo, d->geo.local_len, per, model, skin);
+            d->md->sys.lgv_by_tag = true;                  // the thermostat's noise is keyed by the global ids that travel with the atoms
+            if (d->owns_ctx) d->md->caller_ctx = c;        // queries of this engine order their results on the caller's stream
             d->words.ensure(DD_WORDS);
             d->small.ensure(96);
             d->red.ensure(8);
@@ -609,6 +612,20 @@ struct DdImpl : IDd {
         wait_exchange();
     }
 
+    // The engine's state as dense caller-order arrays (owned atoms first, then the ghosts; positions as the records hold them):
+    // what the rebuild WITH counts starts from -- the first rebuild after a load, and the redo after a message overflowed.
+    // `ids`, optional: engine ids (a send list) to translate into positions of those arrays.
+    void export_caller_arrays(Domain<real> &d, int *ids_to_map = nullptr, int n_ids = 0) {
+        const size_t nt = (size_t)d.n_owned + d.n_ghost;
+        d.x.ensure(3 * nt + 3); d.v.ensure(3 * (size_t)d.n_owned + 3); d.at.ensure(nt + 1); d.gid.ensure(nt + 1);
+        EMDEE_REQUIRE(d.sys().n_total == (int)nt, EMDEE_ERR_STATE, "emdee_dd: domain %d holds %d atoms, its engine %d", d.geo.rank, (int)nt, d.sys().n_total);
+        d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr, d.at.ptr, d.gid.ptr, true);
+        if (ids_to_map && n_ids > 0) {
+            const int *map = d.sys().ids_map();
+            if (map) hipLaunchKernelGGL(k_dd_map_ids, dim3(blocks_for(n_ids, 256)), dim3(256), 0, d.stream(), n_ids, map, ids_to_map);
+        }
+    }
+
     // with_forces = false: the caller follows up with step_after_rebuild, whose fused kernel evaluates them
     void redistribute(bool from_engines, bool with_forces = true) {
         struct Scope {
@@ -625,7 +642,7 @@ struct DdImpl : IDd {
         join_halo();
         if (world == 1 && from_engines && !no_shortcut) {
             // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
-            // none of the ownership passes and their two count read-backs)
+            // none of the ownership passes)
             Domain<real> &d = *dom[0];
             d.md->rebuild();
             if (with_forces) d.md->forces(EMDEE_FORCES, 0);
@@ -634,8 +651,6 @@ struct DdImpl : IDd {
             stat_rebuilds++;
             return;
         }
-        // ---- 0. caller-order copies of the integrated state
-        bool unsorted = false;
         // The count-free protocol rests on every rank neighbouring every other one: the overflow word and the error word of a
         // rank reach everybody in the SAME exchange (message headers), so all commit or all redo.  Today that follows from
         // the <= 3 bricks per dimension of DdGeom::init; should that limit ever go, a far rank would commit while its
@@ -643,16 +658,13 @@ struct DdImpl : IDd {
         bool all_neighbours = true;
         for (auto &pd : dom) all_neighbours = all_neighbours && pd->geo.npeers == world - 1;
         if (from_engines && count_free && all_neighbours && dom[0]->have_caps) {
-            if (redistribute_count_free(with_forces)) return;
-            unsorted = true;                                        // a capacity was exceeded somewhere: everybody redoes it with counts
-            stat_fallback++;
+            if (redistribute_sorted(with_forces)) return;
+            stat_fallback++;                                        // a capacity was exceeded somewhere: everybody redoes it with counts
         }
+        // ---- 0. caller-order copies of the integrated state
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            if (from_engines && !unsorted) {
-                d.x.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3);   // (never grows here: sized at the previous load)
-                d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr);
-            }
+            if (from_engines) export_caller_arrays(d);
             d.mask.ensure((size_t)d.n_owned + 1);
             EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
             // ---- 1. owner of every atom; partition into stay | one bin per peer
@@ -664,12 +676,20 @@ struct DdImpl : IDd {
             pb.npeers = d.geo.npeers;
             for (int p = 0; p <= d.geo.npeers + 1; p++) pb.lo[p] = std::min(1 + p, 1 + d.geo.npeers);
             partition_finish(d, nb1, nblk1, pb);
+            // "an atom left the neighbourhood of its brick" travels with the counts: every rank fails in the same REQUIRE below,
+            // instead of one throwing while its peers walk into the exchange of rows with a rank that is gone
+            hipLaunchKernelGGL(k_dd_flag_counts, dim3(1), dim3(64), 0, d.stream(), d.geo.npeers, d.small.ptr + 95, d.small.ptr + 33);
         }
         exchange_counts_and_read();
         // ---- 2. move the leavers
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            EMDEE_REQUIRE(d.host_small[95] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom of domain %d left the neighbourhood of its brick", d.geo.rank);
+            bool err = d.host_small[95] != 0;
+            for (int p = 0; p < d.geo.npeers; p++) {
+                err = err || (d.host_small[60 + p] & DD_COUNT_ERR) != 0;
+                d.host_small[33 + p] &= ~DD_COUNT_ERR; d.host_small[60 + p] &= ~DD_COUNT_ERR;
+            }
+            EMDEE_REQUIRE(!err, EMDEE_ERR_STATE, "emdee_dd: an atom left the neighbourhood of its brick (seen by domain %d: its own atom or a peer's -- the word travels with the counts, every rank fails here together)", d.geo.rank);
             const int nb = 1 + d.geo.npeers, total = d.host_small[nb], n_stay = d.host_small[1];
             partition_scatter(d, d.n_owned, nb, total, false);
             const int n_leave = total - n_stay;
@@ -731,9 +751,10 @@ struct DdImpl : IDd {
             // room for the ghosts behind the owned atoms (contents preserved by hand: DevBuf::ensure does not)
             grow_keep(d.x, 3 * (size_t)d.n_owned, 3 * (size_t)(d.n_owned + d.n_ghost) + 3, d.stream());
             grow_keep(d.at, (size_t)d.n_owned, (size_t)(d.n_owned + d.n_ghost) + 1, d.stream());
+            grow_keep(d.gid, (size_t)d.n_owned, (size_t)(d.n_owned + d.n_ghost) + 1, d.stream());
             if (total > 0)
                 hipLaunchKernelGGL((k_dd_pack_ghost_rows<real>), dim3(blocks_for(total, 256)), dim3(256), 0, d.stream(), total,
-                                   d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), d.x.ptr, d.at.ptr,
+                                   d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), d.x.ptr, d.at.ptr, d.gid.ptr,
                                    reinterpret_cast<GhostRow<real> *>(d.sendbuf.ptr), d.codes.ptr);
         }
         exchange_rows(sizeof(GhostRow<real>));
@@ -743,7 +764,7 @@ struct DdImpl : IDd {
             if (d.n_ghost > 0)
                 hipLaunchKernelGGL((k_dd_unpack_ghost_rows<real>), dim3(blocks_for(d.n_ghost, 256)), dim3(256), 0, d.stream(), d.n_ghost,
                                    reinterpret_cast<const GhostRow<real> *>(d.recvbuf.ptr), d.x.ptr + 3 * (size_t)d.n_owned,
-                                   d.at.ptr + d.n_owned);
+                                   d.at.ptr + d.n_owned, d.gid.ptr + d.n_owned);
             load_engine(d, with_forces);
         }
         stat_rebuilds++;
@@ -761,7 +782,7 @@ struct DdImpl : IDd {
         d.mig_caps.debug_inject = d.gs_caps.debug_inject = d.gr_caps.debug_inject = 0;
 #ifdef EMDEE_BOUNDS
         // the checker's own test: pack ghost rows with the send list indexed by the counts although a message overflowed
-        // (what k_dd_pack_ghost_rows_padded did before 2d85cf1 -- an out-of-range index the bounds build must report, not use)
+        // (what the padded ghost pack did before 2d85cf1 -- an out-of-range index the bounds build must report, not use)
         if (const char *e = std::getenv("EMDEE_BOUNDS_INJECT")) d.gs_caps.debug_inject = std::string(e) == "ghost_pack" ? 1 : 0;
 #endif
         for (int p = 0; p < np; p++) {
@@ -771,15 +792,29 @@ struct DdImpl : IDd {
         }
         d.have_caps = n_global > 0;       // (the first load runs before the global count is known)
     }
-    // step 4 of a rebuild: bin, sort, neighbour list (forces); buffers of the per-step messages; capacities of the next rebuild
+    // slots an engine needs for its next rebuild in its own order: the state, the arrivals' and the ghosts' capacities behind it
+    size_t edit_slots(const Domain<real> &d, size_t n_now) const {
+        const int np = d.geo.npeers;
+        return (n_now + PART_BLOCK) / PART_BLOCK * PART_BLOCK + PART_BLOCK + (size_t)d.mig_caps.start[np] + (size_t)d.gr_caps.start[np];
+    }
+    // step 4 of a rebuild with counts: bin, sort, neighbour list (forces) from the caller-order arrays
     void load_engine(Domain<real> &d, bool with_forces) {
+        set_caps(d);
+        // (room for the rebuilds to come: atoms drift in and out, the ghost capacities follow the ghost counts)
+        const size_t n_now = (size_t)d.n_owned + d.n_ghost;
+        d.sys().cap_hint = d.have_caps ? edit_slots(d, n_now + n_now / 16 + 1024) + (size_t)d.gr_caps.start[d.geo.npeers] / 8 : 0;
+        d.md->tags_user = reinterpret_cast<const long long *>(d.gid.ptr);
         d.md->defer_forces = !with_forces;
         d.md->set_state(d.n_owned, d.n_ghost, d.x.ptr, d.v.ptr, d.at.ptr, nullptr);
         d.md->defer_forces = false;
-        if (lgv_on) d.md->set_langevin_ids(reinterpret_cast<const int64_t *>(d.gid.ptr));
+        d.md->tags_user = nullptr;
+        for (int p = 0; p <= d.geo.npeers; p++) d.plan.ghost_id[p] = d.n_owned + d.plan.recv_start[p];
+        finish_rebuild(d);
+    }
+    // buffers of the per-step messages (the padded messages of the next rebuild share them), the guard words
+    void finish_rebuild(Domain<real> &d) {
         d.since_build = 0;
-        set_caps(d);
-        // per-step messages: header + 3 reals per atom and peer; the padded messages of the next rebuild share the buffers
+        // per-step messages: header + 3 reals per atom and peer
         const size_t w = sizeof(real);
         const int np = d.geo.npeers;
         const size_t pad_s = std::max(dd_pad_total(d.mig_caps, sizeof(MigRow<real>)), dd_pad_total(d.gs_caps, sizeof(GhostRow<real>)));
@@ -789,37 +824,73 @@ struct DdImpl : IDd {
         EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
     }
 
-    // A rebuild without count exchanges (dd_kernels.hpp, "count-free rebuild messages"): two padded exchanges, device-side
-    // counts in between, ONE read-back.  False: a capacity was exceeded on some rank -- every rank sees that in the headers it
-    // received, nothing has been committed (the new owned arrays were written to the spare buffers), and the caller redoes the
-    // rebuild with exact counts from the caller-order copies made here.
-    bool redistribute_count_free(bool with_forces) {
+    // A rebuild in the engines' own order (dd_kernels.hpp): two padded exchanges, device-side counts throughout, the engine's
+    // own re-sort with the leavers struck out and the arrivals and ghosts appended, ONE read-back (with the build's words).
+    // False: a message capacity was exceeded on some rank -- every rank sees that in the headers it received, every engine
+    // has rolled back to the state it had, and the caller redoes the rebuild with exact counts.
+    bool redistribute_sorted(bool with_forces) {
         const size_t mrow = sizeof(MigRow<real>), grow = sizeof(GhostRow<real>);
-        for (auto &pd : dom) {
-            Domain<real> &d = *pd;
-            const int np = d.geo.npeers, n_up = d.n_owned + d.mig_caps.start[np];
-            d.x.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3);
-            d.sys().unsort(d.x.ptr, d.v.ptr, nullptr, nullptr, nullptr);
-            d.mask.ensure((size_t)n_up + 1);
+        struct Slots { int n, q_arr, mig, gr, ghost_base, n_items, nblk1, nblk_arr, nblk_g; };
+        std::vector<Slots> S(dom.size());
+        for (size_t l = 0; l < dom.size(); l++) {
+            Domain<real> &d = *dom[l];
+            const int np = d.geo.npeers;
+            Slots &e = S[l];
+            e.n = d.sys().n_total;
+            e.mig = d.mig_caps.start[np]; e.gr = d.gr_caps.start[np];
+            e.q_arr = std::max(1, (e.n + PART_BLOCK - 1) / PART_BLOCK) * PART_BLOCK;
+            e.nblk1 = e.q_arr / PART_BLOCK;
+            e.nblk_arr = std::max(1, (e.mig + PART_BLOCK - 1) / PART_BLOCK);
+            e.nblk_g = e.nblk1 + e.nblk_arr;
+            e.ghost_base = e.q_arr + e.mig;
+            e.n_items = e.ghost_base + e.gr;
+            if (!d.sys().edit_fits(e.n_items)) {
+                // This engine's arrays do not hold the slots (the state grew past the room its last load left, or that load was the
+                // very first one): load it again from its own state with room to spare -- a local matter, the peers need not
+                // know (same atoms, same order), and the rebuild goes on in the engine's order like everybody's.
+                export_caller_arrays(d);
+                d.sys().cap_hint = edit_slots(d, (size_t)e.n + e.n / 16 + 1024) + (size_t)e.gr / 8;
+                d.md->tags_user = reinterpret_cast<const long long *>(d.gid.ptr);
+                d.md->defer_forces = true;
+                d.md->set_state(d.n_owned, d.n_ghost, d.x.ptr, d.v.ptr, d.at.ptr, nullptr);
+                d.md->defer_forces = false;
+                d.md->tags_user = nullptr;
+                stat_regrown++;
+                EMDEE_REQUIRE(d.sys().edit_fits(e.n_items), EMDEE_ERR_STATE, "emdee_dd: domain %d cannot re-sort %d slots in place", d.geo.rank, e.n_items);
+            }
+        }
+        for (size_t l = 0; l < dom.size(); l++) {
+            Domain<real> &d = *dom[l];
+            const Slots &e = S[l];
+            NbSystem<real> &sy = d.sys();
+            const int np = d.geo.npeers, nb1 = 1 + np, nb2 = std::max(1, d.geo.ghost_nbins);
+            d.keep.ensure((size_t)e.n_items + 1);
+            d.mask.ensure((size_t)e.q_arr + 1);
+            d.gmask.ensure((size_t)e.q_arr + (size_t)e.nblk_arr * PART_BLOCK + 1);
             d.w.ensure(DDW_COUNT);
+            d.small2.ensure(96);
+            d.counts.ensure((size_t)nb1 * e.nblk1 + 2);
+            d.counts2.ensure((size_t)nb2 * e.nblk_g + 2);
+            d.ids.ensure((size_t)std::max(e.mig + PART_BLOCK, d.gs_caps.start[np]) + 1);
+            d.bins.ensure((size_t)d.gs_caps.start[np] + 1);
+            d.codes.ensure((size_t)d.gs_caps.start[np] + 1);
             EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
-            // ---- 1. owner of every atom; stable partition into stay | one bin per peer (every atom sits in exactly one bin)
-            const int nb1 = 1 + np, nblk1 = partition_prepare(d, d.n_owned, nb1);
-            if (d.n_owned > 0)
-                hipLaunchKernelGGL((k_dd_classify<real>), dim3(nblk1), dim3(PART_BLOCK), 0, d.stream(), d.n_owned, d.x.ptr,
-                                   d.geo.template device<real>(), d.mask.ptr, d.small.ptr + 95, nb1, nblk1, d.counts.ptr);
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.counts.ptr, 0, ((size_t)nb1 * e.nblk1 + 1) * sizeof(int), d.stream()));
+            EMDEE_HIP_CHECK(hipMemsetAsync(d.counts2.ptr, 0, ((size_t)nb2 * e.nblk_g + 1) * sizeof(int), d.stream()));
+            // ---- 1. owner of every atom, where the engine keeps it; the ghost directions of those that stay
+            hipLaunchKernelGGL((k_dd_classify_sorted<real>), dim3(e.nblk1), dim3(PART_BLOCK), 0, d.stream(), e.n, sy.n_owned, sy.perm.ptr,
+                               sy.rec.ptr, d.geo.template device<real>(), d.keep.ptr, d.mask.ptr, d.gmask.ptr, d.small.ptr + 95, nb1,
+                               e.nblk1, d.counts.ptr, nb2, e.nblk_g, d.counts2.ptr);
             DdBins pb{};
             pb.npeers = np;
             for (int p = 0; p <= np + 1; p++) pb.lo[p] = std::min(1 + p, 1 + np);
-            partition_finish(d, nb1, nblk1, pb);
-            d.ids.ensure((size_t)std::max(n_up, d.gs_caps.start[np]) + 1);
-            d.bins.ensure((size_t)d.gs_caps.start[np] + 1);
-            d.codes.ensure((size_t)d.gs_caps.start[np] + 1);
-            partition_scatter(d, d.n_owned, nb1, d.n_owned, false);
+            partition_finish(d, nb1, e.nblk1, pb);
+            hipLaunchKernelGGL(k_part_scatter, dim3(e.nblk1), dim3(PART_BLOCK), 0, d.stream(), e.q_arr, d.mask.ptr, nb1, e.nblk1,
+                               d.counts.ptr, d.ids.ptr, (int *)nullptr, (const int *)nullptr, e.mig + PART_BLOCK);
             // ---- 2. the leavers travel in padded messages
-            const int nt = std::max(1, std::max(np, d.mig_caps.start[np]));
-            hipLaunchKernelGGL((k_dd_pack_migrants_padded<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
-                               d.small.ptr, d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, d.sendbuf.ptr);
+            const int nt = std::max(1, std::max(np, e.mig));
+            hipLaunchKernelGGL((k_dd_pack_migrants_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
+                               d.small.ptr, d.ids.ptr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr, d.sendbuf.ptr);
             for (int p = 0; p < np; p++) {
                 d.xf.soff[p] = d.xf.roff[p] = dd_pad_msg_begin(d.mig_caps, p, mrow);
                 d.xf.sbytes[p] = d.xf.rbytes[p] = dd_pad_msg_bytes(d.mig_caps, p, mrow);
@@ -830,33 +901,26 @@ struct DdImpl : IDd {
         }
         exchange();
         wait_exchange();
-        for (auto &pd : dom) {
-            Domain<real> &d = *pd;
-            const int np = d.geo.npeers, n_up = d.n_owned + d.mig_caps.start[np];
-            hipLaunchKernelGGL((k_dd_migrant_counts<real>), dim3(1), dim3(64), 0, d.stream(), d.mig_caps, d.small.ptr, d.small.ptr + 95,
-                               d.recvbuf.ptr, d.w.ptr);
-            const size_t room = (size_t)n_up + (size_t)d.gr_caps.start[np];      // owned + ghosts of the new state
-            d.x2.ensure(3 * room + 3); d.v2.ensure(3 * (size_t)n_up + 3); d.at2.ensure(room + 1); d.gid2.ensure((size_t)n_up + 1);
-            hipLaunchKernelGGL((k_dd_assemble_padded<real>), dim3(blocks_for(std::max(1, n_up), 256)), dim3(256), 0, d.stream(), n_up,
-                               d.mig_caps, d.w.ptr, d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, d.recvbuf.ptr, d.x2.ptr, d.v2.ptr,
-                               d.at2.ptr, d.gid2.ptr);
-            // ---- 3. ghosts: which neighbours need which of my (new) atoms -- their number is a device word
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
-            const int n_sel = d.geo.ghost_nbins > 0 ? n_up : 0, nb2 = std::max(1, d.geo.ghost_nbins);
-            const int nblk2 = partition_prepare(d, n_sel, nb2);
-            if (n_sel > 0)
-                hipLaunchKernelGGL((k_dd_ghost_mask<real>), dim3(nblk2), dim3(PART_BLOCK), 0, d.stream(), n_sel, d.x2.ptr,
-                                   d.geo.template device<real>(), d.mask.ptr, nb2, nblk2, d.counts.ptr, d.w.ptr + DDW_NNEW);
+        for (size_t l = 0; l < dom.size(); l++) {
+            Domain<real> &d = *dom[l];
+            const Slots &e = S[l];
+            NbSystem<real> &sy = d.sys();
+            const int np = d.geo.npeers, nb2 = std::max(1, d.geo.ghost_nbins);
+            // ---- 3. arrivals behind the old state; ghosts: which neighbours need which of my (new) atoms
+            hipLaunchKernelGGL((k_dd_unpack_arrivals<real>), dim3(e.nblk_arr), dim3(PART_BLOCK), 0, d.stream(), d.mig_caps, d.small.ptr,
+                               d.small.ptr + 95, d.recvbuf.ptr, d.n_owned, e.q_arr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr,
+                               d.keep.ptr, d.gmask.ptr, d.geo.template device<real>(), nb2, e.nblk_g, d.counts2.ptr, e.nblk1, d.w.ptr);
             DdBins pb{};
             pb.npeers = np;
             for (int p = 0; p <= np + 1; p++) pb.lo[p] = d.geo.peer_bin_lo[std::min(p, np)];
-            partition_finish(d, nb2, nblk2, pb);
-            if (n_sel > 0)
-                hipLaunchKernelGGL(k_part_scatter, dim3(nblk2), dim3(PART_BLOCK), 0, d.stream(), n_sel, d.mask.ptr, nb2, nblk2,
-                                   d.counts.ptr, d.ids.ptr, d.bins.ptr, d.w.ptr + DDW_NNEW, d.gs_caps.start[np]);
+            d.scanner.run(d.counts2.ptr, (size_t)nb2 * e.nblk_g + 1, d.stream());
+            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, d.stream(), nb2, e.nblk_g, d.counts2.ptr, d.small2.ptr, pb, d.small2.ptr + 33);
+            if (d.geo.ghost_nbins > 0)
+                hipLaunchKernelGGL(k_part_scatter, dim3(e.nblk_g), dim3(PART_BLOCK), 0, d.stream(), e.ghost_base, d.gmask.ptr, nb2, e.nblk_g,
+                                   d.counts2.ptr, d.ids.ptr, d.bins.ptr, (const int *)nullptr, d.gs_caps.start[np]);
             const int nt = std::max(1, std::max(np, d.gs_caps.start[np]));
-            hipLaunchKernelGGL((k_dd_pack_ghost_rows_padded<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.gs_caps,
-                               d.small.ptr + 33, d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), d.x2.ptr, d.at2.ptr,
+            hipLaunchKernelGGL((k_dd_pack_ghost_rows_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.gs_caps,
+                               d.small2.ptr + 33, d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), sy.rec.ptr, sy.te.ptr, sy.tag.ptr,
                                d.sendbuf.ptr, d.codes.ptr, d.w.ptr);
             for (int p = 0; p < np; p++) {
                 d.xf.soff[p] = dd_pad_msg_begin(d.gs_caps, p, grow); d.xf.sbytes[p] = dd_pad_msg_bytes(d.gs_caps, p, grow);
@@ -868,25 +932,43 @@ struct DdImpl : IDd {
         }
         exchange();
         wait_exchange();
+        // ---- 4. the engines re-sort their own slots and build their lists; the counts come back with the build's words
+        std::vector<char> built(dom.size(), 0);
+        for (size_t l = 0; l < dom.size(); l++) {
+            Domain<real> &d = *dom[l];
+            const Slots &e = S[l];
+            NbSystem<real> &sy = d.sys();
+            const int np = d.geo.npeers;
+            hipLaunchKernelGGL((k_dd_unpack_ghost_rows_sorted<real>), dim3(blocks_for(std::max(1, e.gr), 256)), dim3(256), 0, d.stream(),
+                               d.gs_caps, d.gr_caps, d.small2.ptr + 33, d.recvbuf.ptr, e.ghost_base, sy.rec.ptr, sy.te.ptr, sy.vel.ptr,
+                               sy.pitch, sy.tag.ptr, d.keep.ptr, d.w.ptr);
+            typename NbSystem<real>::EditWords extra;
+            extra.dev = d.w.ptr; extra.n = DDW_COUNT; extra.host = d.host_w;
+            built[l] = sy.resort_edit(e.n_items, d.keep.ptr, e.ghost_base, np > 0, d.w.ptr + DDW_NLIVE, extra) ? 1 : 0;
+        }
         bool over = false;
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            hipLaunchKernelGGL((k_dd_ghost_counts<real>), dim3(1), dim3(64), 0, d.stream(), d.gs_caps, d.gr_caps, d.small.ptr + 33,
-                               d.recvbuf.ptr, d.w.ptr);
-            read_back_words(d.ctx, d.stream(), d.w.ptr, DDW_COUNT, d.host_w);
             EMDEE_REQUIRE(d.host_w[DDW_ERR] == 0, EMDEE_ERR_STATE, "emdee_dd: an atom left the neighbourhood of its brick (seen by domain %d: its own atom or a peer's -- the word travels with the ghost messages, every rank fails here together)", d.geo.rank);
             over = over || d.host_w[DDW_OVER] != 0;
         }
-        // the same word on every rank (k_dd_ghost_counts): ranks in separate processes have nothing but that to agree on the
-        // redo, so the validation mode -- all domains here -- insists on it
+        // the same word on every rank (k_dd_unpack_ghost_rows_sorted): ranks in separate processes have nothing but that to agree on
+        // the redo, so the validation mode -- all domains here -- insists on it
         for (auto &pd : dom)
             EMDEE_REQUIRE((pd->host_w[DDW_OVER] != 0) == over, EMDEE_ERR_STATE,
                           "emdee_dd: the domains disagree on whether a rebuild message overflowed (domain %d)", pd->geo.rank);
-        if (over) return false;
-        for (auto &pd : dom) {
-            Domain<real> &d = *pd;
+        if (over) {
+            for (auto &pd : dom) pd->sys().rollback_edit();
+            return false;
+        }
+        for (size_t l = 0; l < dom.size(); l++) {
+            Domain<real> &d = *dom[l];
+            const Slots &e = S[l];
+            NbSystem<real> &sy = d.sys();
             const int np = d.geo.npeers;
-            d.x.swap(d.x2); d.v.swap(d.v2); d.at.swap(d.at2); d.gid.swap(d.gid2);
+            EMDEE_REQUIRE(d.host_w[DDW_NLIVE] == d.host_w[DDW_NNEW] + d.host_w[DDW_NGHOST], EMDEE_ERR_STATE,
+                          "emdee_dd: domain %d re-sorted %d atoms, its messages say %d + %d", d.geo.rank, d.host_w[DDW_NLIVE], d.host_w[DDW_NNEW], d.host_w[DDW_NGHOST]);
+            sy.commit_edit(d.host_w[DDW_NLIVE]);
             d.n_owned = d.host_w[DDW_NNEW];
             stat_migrated += d.host_w[DDW_NLEAVE];
             d.plan = DdPlan{};
@@ -895,21 +977,33 @@ struct DdImpl : IDd {
                 d.plan.send_start[p + 1] = d.plan.send_start[p] + d.host_w[DDW_GSEND + p];
                 d.plan.recv_start[p + 1] = d.plan.recv_start[p] + d.host_w[DDW_GRECV + p];
             }
+            for (int p = 0; p <= np; p++) d.plan.ghost_id[p] = e.ghost_base + d.gr_caps.start[p];   // (the capacities THIS rebuild ran with)
             d.n_send = d.plan.send_start[np];
             d.n_ghost = d.plan.recv_start[np];
             EMDEE_REQUIRE(d.n_send == d.host_w[DDW_NSEND] && d.n_ghost == d.host_w[DDW_NGHOST], EMDEE_ERR_STATE, "emdee_dd: ghost counts inconsistent");
-            if (d.n_ghost > 0)
-                hipLaunchKernelGGL((k_dd_unpack_ghost_rows_padded<real>), dim3(blocks_for(d.n_ghost, 256)), dim3(256), 0, d.stream(),
-                                   d.n_ghost, d.plan, d.gr_caps, d.recvbuf.ptr, d.x.ptr + 3 * (size_t)d.n_owned, d.at.ptr + d.n_owned);
-            load_engine(d, with_forces);
+            d.md->n_ghost = d.n_ghost;
+            d.md->since_build = 0;
+            d.md->current_mask = 0;
+            if (!built[l]) {
+                // an engine on the direct kernels (they count atoms on the host): its re-sorted state is complete but has no list --
+                // a load from its own state, which nobody else needs to know about; the send list follows the new numbering
+                export_caller_arrays(d, d.ids.ptr, d.n_send);
+                load_engine(d, with_forces);
+                continue;
+            }
+            if (with_forces && sy.n_total > 0) { d.md->forces(EMDEE_FORCES, 0); }
+            set_caps(d);
+            finish_rebuild(d);
         }
         stat_rebuilds++;
         stat_fast++;
         return true;
     }
+    int64_t stat_regrown = 0;
 
     static void grow_keep(DevBuf<real> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
     static void grow_keep(DevBuf<emdee_lj_atom> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
+    static void grow_keep(DevBuf<long long> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
     template <typename T>
     static void grow_keep_t(DevBuf<T> &b, size_t keep, size_t want, hipStream_t s) {
         if (want <= b.cap) return;
@@ -1046,8 +1140,7 @@ struct DdImpl : IDd {
         lgv_on = gamma > 0.0;
         lgv_gamma = gamma; lgv_T = temperature; lgv_seed = seed; lgv_first = first_step;
         for (auto &d : dom) {
-            d->md->set_langevin(gamma, temperature, seed, first_step);
-            d->md->set_langevin_ids(lgv_on && loaded ? reinterpret_cast<const int64_t *>(d->gid.ptr) : nullptr);
+            d->md->set_langevin(gamma, temperature, seed, first_step);   // (the noise is keyed by the global ids that travel with the atoms)
         }
     }
 
@@ -1233,19 +1326,18 @@ struct DdImpl : IDd {
         Domain<real> &d = local(l);
         EMDEE_REQUIRE(loaded, EMDEE_ERR_STATE, "emdee_dd_get_state: call emdee_dd_load first");
         join_halo();
-        const size_t n = (size_t)d.n_owned;
-        d.f.ensure(3 * n + 3);
-        // caller-order copies of the whole domain (positions include the ghosts) into scratch, owned part out
-        d.x2.ensure(3 * (size_t)(d.n_owned + d.n_ghost) + 3); d.v2.ensure(3 * n + 3);
-        d.sys().unsort(d.x2.ptr, d.v2.ptr, d.f.ptr, nullptr, nullptr);
+        const size_t n = (size_t)d.n_owned, nt = n + (size_t)d.n_ghost;
+        // caller-order copies of the whole domain (positions and ids include the ghosts) into scratch, owned part out
+        d.f.ensure(3 * n + 3); d.x2.ensure(3 * nt + 3); d.v2.ensure(3 * n + 3); d.gid2.ensure(nt + 1);
+        d.sys().unsort(d.x2.ptr, d.v2.ptr, d.f.ptr, nullptr, nullptr, nullptr, d.gid2.ptr);
+        FenceOut fence(user_ctx, d.stream());
         hipStream_t s = d.stream();
         if (n > 0) {
             if (pos) EMDEE_HIP_CHECK(hipMemcpyAsync(pos, d.x2.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
             if (vel) EMDEE_HIP_CHECK(hipMemcpyAsync(vel, d.v2.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
             if (frc) EMDEE_HIP_CHECK(hipMemcpyAsync(frc, d.f.ptr, 3 * n * sizeof(real), hipMemcpyDeviceToDevice, s));
-            if (gids) EMDEE_HIP_CHECK(hipMemcpyAsync(gids, d.gid.ptr, n * sizeof(long long), hipMemcpyDeviceToDevice, s));
+            if (gids) EMDEE_HIP_CHECK(hipMemcpyAsync(gids, d.gid2.ptr, n * sizeof(long long), hipMemcpyDeviceToDevice, s));
         }
-        EMDEE_HIP_CHECK(hipStreamSynchronize(s));
     }
     void stats(int64_t out[4]) override {
         out[0] = stat_rebuilds; out[1] = stat_batches; out[2] = stat_cancelled; out[3] = stat_migrated;

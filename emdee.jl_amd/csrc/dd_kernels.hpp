@@ -41,9 +41,10 @@ struct MigRow {                       // an atom changing owner
     long long gid;
 };
 template <typename real>
-struct GhostRow {                     // a ghost as first sent: shifted position + LJAtom
-    real x[3];
+struct GhostRow {                     // a ghost as first sent: shifted position + LJAtom + global id (the engines order a cell's
+    real x[3];                        // atoms by it, ghosts included: NbSystem::tag)
     float hs, te;
+    long long gid;
 };
 
 // prefix of atoms per peer for the per-step messages (message p = DD_HDR bytes + 3 reals per atom)
@@ -51,6 +52,7 @@ struct DdPlan {
     int npeers;
     int send_start[DD_MAX_PEERS + 1];
     int recv_start[DD_MAX_PEERS + 1];
+    int ghost_id[DD_MAX_PEERS + 1];   // engine id of the first ghost received from peer p (the ids of a peer's ghosts are consecutive)
 };
 // message p begins at byte p DD_HDR + 3 w start[p] and holds DD_HDR + 3 w (start[p+1] - start[p]) bytes
 static inline size_t dd_msg_begin(const int *start, int p, size_t w) { return (size_t)p * DD_HDR + (size_t)start[p] * 3 * w; }
@@ -78,6 +80,10 @@ __device__ __forceinline__ void part_count_block(unsigned m, int nbins, int nblo
 }
 
 // ------------------------------------------------------------------------------------ ownership
+// coordinate p wrapped into [0, L): ONE function for every ownership pass, so that the rebuild paths agree to the bit
+template <typename real>
+__device__ __forceinline__ real dd_wrap(real p, real L) { return p - L * floor(p / L); }
+
 // Wrap every owned atom into the global box and name the rank whose brick contains it.
 // mask[i] = 1 << bin: bin 0 = stays here, 1 + p = leaves for peer p.  An atom that would have to
 // jump over a brick (cannot happen while the halo exceeds the displacement between rebuilds) raises *err.
@@ -90,8 +96,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_classify(int n, real *__restr
         int c[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            real p = x[3 * (size_t)i + d];
-            p -= g.L[d] * floor(p / g.L[d]);
+            const real p = dd_wrap(x[3 * (size_t)i + d], g.L[d]);
             x[3 * (size_t)i + d] = p;
             c[d] = min(max((int)floor(p / g.width[d]), 0), g.grid[d] - 1);
         }
@@ -175,6 +180,19 @@ static __global__ void k_part_starts(int nbins, int nblocks, const int *__restri
     if (t < pb.npeers) peer_count[t] = offs[(size_t)pb.lo[t + 1] * nblocks] - offs[(size_t)pb.lo[t] * nblocks];
 }
 
+// the counted rebuild: my error word rides on the counts I send (bit 30 of every per-peer count), so that all ranks see it
+// in the exchange of counts and fail together
+constexpr int DD_COUNT_ERR = 1 << 30;
+static __global__ void k_dd_flag_counts(int npeers, const int *__restrict__ err, int *__restrict__ peer_count) {
+    const int t = threadIdx.x;
+    if (t < npeers && *err != 0) peer_count[t] |= DD_COUNT_ERR;
+}
+// engine ids -> positions in the dense caller-order arrays (NbSystem::ids_map)
+static __global__ void k_dd_map_ids(int n, const int *__restrict__ map, int *__restrict__ ids) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) ids[k] = map[ids[k]];
+}
+
 // ------------------------------------------------------------------------------------ migration rows
 template <typename real>
 __global__ void k_dd_pack_migrants(int first, int total, const int *__restrict__ ids, const real *__restrict__ x,
@@ -221,8 +239,8 @@ __global__ void k_dd_assemble_owned(int n_stay, int n_arrive, const int *__restr
 template <typename real>
 __global__ void k_dd_pack_ghost_rows(int n, const int *__restrict__ ids, const int *__restrict__ bins, DdDev<real> g,
                                      const real *__restrict__ x,
-                                     const emdee_lj_atom *__restrict__ atoms, GhostRow<real> *__restrict__ rows,
-                                     int *__restrict__ codes) {
+                                     const emdee_lj_atom *__restrict__ atoms, const long long *__restrict__ gid,
+                                     GhostRow<real> *__restrict__ rows, int *__restrict__ codes) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int i = ids[k], dir = g.bin_dir[bins[k]];
@@ -230,13 +248,14 @@ __global__ void k_dd_pack_ghost_rows(int n, const int *__restrict__ ids, const i
 #pragma unroll
     for (int d = 0; d < 3; d++) r.x[d] = x[3 * (size_t)i + d] + g.shift[dir][d];
     r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
+    r.gid = gid[i];
     rows[k] = r;
     codes[k] = dir;
 }
 
 template <typename real>
 __global__ void k_dd_unpack_ghost_rows(int n, const GhostRow<real> *__restrict__ rows, real *__restrict__ x,
-                                       emdee_lj_atom *__restrict__ atoms) {
+                                       emdee_lj_atom *__restrict__ atoms, long long *__restrict__ gid) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const GhostRow<real> r = rows[k];
@@ -245,16 +264,27 @@ __global__ void k_dd_unpack_ghost_rows(int n, const GhostRow<real> *__restrict__
     emdee_lj_atom a;
     a.half_sigma = r.hs; a.twice_sqrt_eps = r.te;
     atoms[k] = a;
+    gid[k] = r.gid;
 }
 
-// ------------------------------------------------------------------------------------ count-free rebuild messages
-// Round 2 exchanged the row counts of a migration and of a ghost selection first (two extra RCCL groups and two blocking
-// read-backs per rebuild) because the counts size the messages.  Here a message has a CAPACITY both ends know without
-// talking -- migrants: a fixed number of rows per peer; ghost rows: the count of the previous rebuild plus an eighth --
-// and starts with a 16-byte header {rows, overflow, 0, 0}; everything between the two exchanges runs on device-side
-// counts over upper-bound grids, and ONE read-back at the end tells the host all of them.  "overflow" is raised in ALL
-// messages of a rank whose rows for some peer exceed the capacity; every rank neighbours every other one, so everybody
-// learns of it in the same exchange and the whole rebuild is redone with exact counts (dd.hpp).
+// ------------------------------------------------------------------------------------ a rebuild in the engine's own order
+// Rounds 2-4 rebuilt a domain by way of caller-order arrays: un-sort the engine's state, find the owners, assemble new
+// caller arrays (stayers + arrivals), select the ghosts, append theirs, load the engine from scratch -- with the row counts
+// of the two exchanges either exchanged first (round 2: two more RCCL groups, two more read-backs) or read back in between
+// (round 3: capacity-padded messages, one read-back for the counts and one for the build).  Here nothing leaves the engine's
+// cell order, and the host learns the counts together with the build's own words:
+//   * the ownership pass reads the engine's records where they lie, strikes out the leavers and the old ghosts (keep[] = 0)
+//     and selects the ghost directions of the atoms that stay in the same pass (an atom that stays does not move);
+//   * leavers travel in padded messages {rows, overflow | MigRow ...} as before; the arrivals are written BEHIND the old
+//     state (records, velocity planes, global ids), the rows a message did not use struck out;
+//   * ghost rows likewise: out of the records, in behind the arrivals;
+//   * the engine re-sorts its own slots [0, n_items) without the struck-out ones (NbSystem::resort_edit): nearly sorted
+//     input, the old slot becomes the atom's id, and the number of atoms that gives is a device word until the build's
+//     read-back, which carries the words below along.
+// A message that overflows is seen by every rank in the same exchange (every rank neighbours every other one); the engines
+// have not given up their old state by then (resort_edit keeps it in the spare buffers), so all ranks roll back and redo the
+// rebuild with exact counts -- round 2's path, which the first load and the first rebuild (they fix the capacities) also take.
+// Slots: [0, n) the old state | dead up to q_arr = n rounded up to PART_BLOCK | arrivals, mig capacity | ghosts, ghost capacity.
 constexpr int DD_RHDR = 16;
 struct DdCaps {
     int npeers;
@@ -272,15 +302,83 @@ __device__ __forceinline__ int dd_caps_peer(const DdCaps &c, int t) {
     return p;
 }
 
-// words a count-free rebuild leaves for its one read-back (ints)
+// words a rebuild leaves for its one read-back (ints); DDW_NLIVE: the atoms of the re-sorted state (written by the engine)
 constexpr int DDW_NSTAY = 0, DDW_NNEW = 1, DDW_ERR = 2, DDW_OVER = 3, DDW_NLEAVE = 4, DDW_NARRIVE = 5, DDW_NSEND = 6, DDW_NGHOST = 7,
-              DDW_GSEND = 8, DDW_GRECV = 8 + DD_MAX_PEERS, DDW_ARRIVE = 8 + 2 * DD_MAX_PEERS, DDW_COUNT = 8 + 3 * DD_MAX_PEERS;
+              DDW_GSEND = 8, DDW_GRECV = 8 + DD_MAX_PEERS, DDW_ARRIVE = 8 + 2 * DD_MAX_PEERS, DDW_NLIVE = 8 + 3 * DD_MAX_PEERS,
+              DDW_COUNT = 9 + 3 * DD_MAX_PEERS;
 
-// leavers -> padded messages (ids[bin_start[1 + p] + slot], the stable partition's order); headers
+// which neighbours need an owned atom at (x, y, z) as a ghost: bit dir_bin[k] for every direction k whose halo holds it
 template <typename real>
-__global__ void k_dd_pack_migrants_padded(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ ids,
-                                          const real *__restrict__ x, const real *__restrict__ v,
-                                          const emdee_lj_atom *__restrict__ atoms, const long long *__restrict__ gid,
+__device__ __forceinline__ unsigned dd_ghost_bits(const DdDev<real> &g, real x, real y, real z) {
+    const real p[3] = {x, y, z};
+    bool near_lo[3], near_hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        near_lo[d] = g.cut[d] && p[d] < g.lo[d] + g.halo;
+        near_hi[d] = g.cut[d] && p[d] >= g.hi[d] - g.halo;
+    }
+    unsigned m = 0;
+    for (int k = 0; k < g.ndirs; k++) {
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int s = g.dir[k][d];
+            in = in && (s == 0 || (s > 0 ? near_hi[d] : near_lo[d]));
+        }
+        if (in) m |= 1u << g.dir_bin[k];
+    }
+    return m;
+}
+
+// The ownership pass over the engine's own slots (grid: q_arr / PART_BLOCK blocks).  Owned atoms are wrapped into the global
+// box (written back: a leaver's row carries the wrapped position, a stayer's does not change) and named the rank whose brick
+// holds them: lmask = 1 << (1 + peer) for a leaver (bin 0 stays empty: nobody needs the list of those who stay), keep = 1
+// and gmask = the ghost directions for a stayer; ghosts and the slots past n are struck out.
+template <typename real>
+__global__ __launch_bounds__(PART_BLOCK) void k_dd_classify_sorted(int n, int own_limit, const int *__restrict__ perm,
+                                                                   Rec<real> *__restrict__ rec, DdDev<real> g,
+                                                                   unsigned char *__restrict__ keep, unsigned *__restrict__ lmask,
+                                                                   unsigned *__restrict__ gmask, int *__restrict__ err, int nb_leave,
+                                                                   int nblk_leave, int *__restrict__ counts_leave, int nb_ghost,
+                                                                   int nblk_ghost, int *__restrict__ counts_ghost) {
+    const int q = blockIdx.x * PART_BLOCK + threadIdx.x;
+    unsigned lm = 0, gm = 0;
+    unsigned char kp = 0;
+    if (q < n && perm[q] < own_limit) {
+        Rec<real> r = rec[q];
+        real p[3] = {r.x, r.y, r.z};
+        int c[3];
+        bool moved = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const real w = dd_wrap(p[d], g.L[d]);
+            moved = moved || w != p[d];
+            p[d] = w;
+            c[d] = min(max((int)floor(w / g.width[d]), 0), g.grid[d] - 1);
+        }
+        if (moved) { r.x = p[0]; r.y = p[1]; r.z = p[2]; rec[q] = r; }
+        const int dest = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
+        int bin = g.rank_bin[dest];
+        if (bin < 0) { *err = 1; bin = 0; }
+        if (bin == 0) {
+            kp = 1;
+            gm = dd_ghost_bits(g, p[0], p[1], p[2]);
+        } else {
+            lm = 1u << bin;
+        }
+    }
+    keep[q] = kp;
+    lmask[q] = lm;
+    gmask[q] = gm;
+    part_count_block(lm, nb_leave, nblk_leave, counts_leave);
+    part_count_block(gm, nb_ghost, nblk_ghost, counts_ghost);
+}
+
+// leavers -> padded messages (ids[bin_start[1 + p] + slot], the stable partition's order), out of the engine's arrays; headers
+template <typename real>
+__global__ void k_dd_pack_migrants_sorted(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ ids,
+                                          const Rec<real> *__restrict__ rec, const float *__restrict__ te,
+                                          const real *__restrict__ vel, size_t pitch, const long long *__restrict__ tag,
                                           unsigned char *__restrict__ buf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < caps.npeers) {
@@ -294,74 +392,75 @@ __global__ void k_dd_pack_migrants_padded(DdCaps caps, const int *__restrict__ b
     if (slot >= bin_start[2 + p] - bin_start[1 + p]) return;
     if (!EMDEE_BOUND(BS_DD_MIG_PACK, slot, caps.start[p + 1] - caps.start[p])) return;
     const int i = ids[bin_start[1 + p] + slot];
+    const Rec<real> a = rec[i];
     MigRow<real> r;
+    r.x[0] = a.x; r.x[1] = a.y; r.x[2] = a.z;
 #pragma unroll
-    for (int d = 0; d < 3; d++) { r.x[d] = x[3 * (size_t)i + d]; r.v[d] = v[3 * (size_t)i + d]; }
-    r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
-    r.gid = gid[i];
+    for (int d = 0; d < 3; d++) r.v[d] = vel[d * pitch + i];
+    rec_params(rec, te, i, r.hs, r.te);
+    r.gid = tag[i];
     reinterpret_cast<MigRow<real> *>(buf + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[slot] = r;
 }
 
-// after the migrant exchange: w[DDW_NSTAY], w[DDW_NNEW], arrivals per peer, overflow (mine or anybody's), error word
+// After the migrant exchange (grid: blocks of PART_BLOCK over the migrant capacity, at least one): arrival t of the padded
+// receive buffer -> slot q_arr + t behind the old state (record, velocities, global id, ghost directions), unused rows struck
+// out; thread 0: the counts of the migration and the overflow word (mine or anybody's) for the read-back.
 template <typename real>
-__global__ void k_dd_migrant_counts(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ err,
-                                    const unsigned char *__restrict__ recv, int *__restrict__ w) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int over = 0, arrive = 0, leave = 0;
-    for (int p = 0; p < caps.npeers; p++) {
-        const int cap = caps.start[p + 1] - caps.start[p];
+__global__ __launch_bounds__(PART_BLOCK) void k_dd_unpack_arrivals(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ err,
+                                                                   const unsigned char *__restrict__ recv, int n_owned_old, int q_arr,
+                                                                   Rec<real> *__restrict__ rec, float *__restrict__ te,
+                                                                   real *__restrict__ vel, size_t pitch, long long *__restrict__ tag,
+                                                                   unsigned char *__restrict__ keep, unsigned *__restrict__ gmask,
+                                                                   DdDev<real> g, int nb_ghost, int nblk_ghost,
+                                                                   int *__restrict__ counts_ghost, int blk0, int *__restrict__ w) {
+    const int t = blockIdx.x * PART_BLOCK + threadIdx.x;
+    if (t == 0) {
+        int over = 0, arrive = 0, leave = 0;
+        for (int p = 0; p < caps.npeers; p++) {
+            const int cap = caps.start[p + 1] - caps.start[p];
+            const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)) - DD_RHDR);
+            const int out = bin_start[2 + p] - bin_start[1 + p];
+            over |= hdr[1] | (hdr[0] > cap) | (out > cap);
+            const int in = min(max(hdr[0], 0), cap);
+            w[DDW_ARRIVE + p] = in;
+            arrive += in; leave += out;
+        }
+        w[DDW_NSTAY] = n_owned_old - leave;
+        w[DDW_NNEW] = n_owned_old - leave + arrive;
+        w[DDW_ERR] = *err;
+        w[DDW_OVER] = over;
+        w[DDW_NLEAVE] = leave;
+        w[DDW_NARRIVE] = arrive;
+    }
+    unsigned gm = 0;
+    if (t < caps.start[caps.npeers]) {
+        const int p = dd_caps_peer(caps, t), slot = t - caps.start[p], cap = caps.start[p + 1] - caps.start[p];
         const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)) - DD_RHDR);
-        const int out = bin_start[2 + p] - bin_start[1 + p];
-        over |= hdr[1] | (hdr[0] > cap) | (out > cap);
-        const int in = min(max(hdr[0], 0), cap);
-        w[DDW_ARRIVE + p] = in;
-        arrive += in; leave += out;
+        const int q = q_arr + t;
+        unsigned char kp = 0;
+        if (slot < min(max(hdr[0], 0), cap)) {
+            const MigRow<real> r = reinterpret_cast<const MigRow<real> *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[slot];
+            store_rec<real>(rec, te, q, r.x[0], r.x[1], r.x[2], r.hs, r.te);
+#pragma unroll
+            for (int d = 0; d < 3; d++) vel[d * pitch + q] = r.v[d];
+            tag[q] = r.gid;
+            gm = dd_ghost_bits(g, r.x[0], r.x[1], r.x[2]);
+            kp = 1;
+        }
+        keep[q] = kp;
     }
-    w[DDW_NSTAY] = bin_start[1];
-    w[DDW_NNEW] = bin_start[1] + arrive;
-    w[DDW_ERR] = *err;
-    w[DDW_OVER] = over;
-    w[DDW_NLEAVE] = leave;
-    w[DDW_NARRIVE] = arrive;
+    // (the ghost masks of the arrival blocks exist for every thread of the grid: the scatter reads whole blocks)
+    gmask[q_arr + t] = gm;
+    part_count_block(gm, nb_ghost, nblk_ghost, counts_ghost + blk0);
 }
 
-// new owned arrays from device-side counts: stayers (ids[0 .. n_stay)), then the arrivals in peer order
+// ghost rows -> padded messages, out of the engine's arrays; peer_count[p] = entries bound for peer p (k_part_starts), list
+// entry k of peer p sits at sum of the counts before p + slot; codes[k] = direction, for the per-step messages
 template <typename real>
-__global__ void k_dd_assemble_padded(int n_max, DdCaps caps, const int *__restrict__ w, const int *__restrict__ ids,
-                                     const real *__restrict__ x, const real *__restrict__ v, const emdee_lj_atom *__restrict__ atoms,
-                                     const long long *__restrict__ gid, const unsigned char *__restrict__ recv,
-                                     real *__restrict__ x2, real *__restrict__ v2, emdee_lj_atom *__restrict__ atoms2,
-                                     long long *__restrict__ gid2) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_stay = w[DDW_NSTAY], n_new = min(w[DDW_NNEW], n_max);
-    if (k >= n_new) return;
-    if (k < n_stay) {
-        const int i = ids[k];
-#pragma unroll
-        for (int d = 0; d < 3; d++) { x2[3 * (size_t)k + d] = x[3 * (size_t)i + d]; v2[3 * (size_t)k + d] = v[3 * (size_t)i + d]; }
-        atoms2[k] = atoms[i];
-        gid2[k] = gid[i];
-        return;
-    }
-    int a = k - n_stay, p = 0;
-    while (p + 1 < caps.npeers && a >= w[DDW_ARRIVE + p]) { a -= w[DDW_ARRIVE + p]; p++; }
-    if (!EMDEE_BOUND(BS_DD_ASSEMBLE, k, n_max)) return;
-    const MigRow<real> r = reinterpret_cast<const MigRow<real> *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)))[a];
-#pragma unroll
-    for (int d = 0; d < 3; d++) { x2[3 * (size_t)k + d] = r.x[d]; v2[3 * (size_t)k + d] = r.v[d]; }
-    emdee_lj_atom at;
-    at.half_sigma = r.hs; at.twice_sqrt_eps = r.te;
-    atoms2[k] = at;
-    gid2[k] = r.gid;
-}
-
-// ghost rows -> padded messages; peer_count[p] = entries bound for peer p (k_part_starts), list entry k of peer p sits at
-// sum of the counts before p + slot; codes[k] = direction, for the per-step messages
-template <typename real>
-__global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__ peer_count, const int *__restrict__ ids,
-                                            const int *__restrict__ bins, DdDev<real> g, const real *__restrict__ x,
-                                            const emdee_lj_atom *__restrict__ atoms, unsigned char *__restrict__ buf,
-                                            int *__restrict__ codes, const int *__restrict__ w_over) {
+__global__ void k_dd_pack_ghost_rows_sorted(DdCaps caps, const int *__restrict__ peer_count, const int *__restrict__ ids,
+                                            const int *__restrict__ bins, DdDev<real> g, const Rec<real> *__restrict__ rec,
+                                            const float *__restrict__ te, const long long *__restrict__ tag,
+                                            unsigned char *__restrict__ buf, int *__restrict__ codes, const int *__restrict__ w_over) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     int over = w_over[DDW_OVER];
     for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
@@ -382,50 +481,59 @@ __global__ void k_dd_pack_ghost_rows_padded(DdCaps caps, const int *__restrict__
     for (int q = 0; q < p; q++) k += peer_count[q];
     if (!EMDEE_BOUND(BS_DD_GHOST_PACK, k, caps.start[caps.npeers])) return;   // the send list (ids, bins, codes) holds start[npeers] entries
     const int i = ids[k], dir = g.bin_dir[bins[k]];
+    const Rec<real> a = rec[i];
     GhostRow<real> r;
-#pragma unroll
-    for (int d = 0; d < 3; d++) r.x[d] = x[3 * (size_t)i + d] + g.shift[dir][d];
-    r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
+    r.x[0] = a.x + g.shift[dir][0]; r.x[1] = a.y + g.shift[dir][1]; r.x[2] = a.z + g.shift[dir][2];
+    rec_params(rec, te, i, r.hs, r.te);
+    r.gid = tag[i];
     reinterpret_cast<GhostRow<real> *>(buf + dd_pad_begin(caps, p, sizeof(GhostRow<real>)))[slot] = r;
     codes[k] = dir;
 }
 
-// after the ghost exchange: send / receive counts per peer, totals, overflow of either exchange
+// After the ghost exchange (grid: blocks over the ghost capacity, at least one): row t of the padded receive buffer -> slot
+// ghost_base + t (record, global id), unused rows struck out; thread 0: send / receive counts per peer, totals, the overflow
+// and error words of either exchange (mine or a peer's: the same words on every rank).
 template <typename real>
-__global__ void k_dd_ghost_counts(DdCaps scaps, DdCaps rcaps, const int *__restrict__ peer_count,
-                                  const unsigned char *__restrict__ recv, int *__restrict__ w) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int over = w[DDW_OVER], nsend = 0, nghost = 0, err = w[DDW_ERR];
-    for (int p = 0; p < scaps.npeers; p++) {
-        const int rcap = rcaps.start[p + 1] - rcaps.start[p], scap = scaps.start[p + 1] - scaps.start[p];
-        const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
-        over |= hdr[1] | (hdr[0] > rcap) | (peer_count[p] > scap);
-        err |= hdr[2];
-        w[DDW_GSEND + p] = peer_count[p];
-        w[DDW_GRECV + p] = hdr[0];
-        nsend += peer_count[p];
-        nghost += hdr[0];
+__global__ void k_dd_unpack_ghost_rows_sorted(DdCaps scaps, DdCaps rcaps, const int *__restrict__ peer_count,
+                                              const unsigned char *__restrict__ recv, int ghost_base, Rec<real> *__restrict__ rec,
+                                              float *__restrict__ te, real *__restrict__ vel, size_t pitch,
+                                              long long *__restrict__ tag, unsigned char *__restrict__ keep, int *__restrict__ w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        int over = w[DDW_OVER], nsend = 0, nghost = 0, err = w[DDW_ERR];
+        for (int p = 0; p < scaps.npeers; p++) {
+            const int rcap = rcaps.start[p + 1] - rcaps.start[p], scap = scaps.start[p + 1] - scaps.start[p];
+            const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
+            over |= hdr[1] | (hdr[0] > rcap) | (peer_count[p] > scap);
+            err |= hdr[2];
+            w[DDW_GSEND + p] = peer_count[p];
+            w[DDW_GRECV + p] = hdr[0];
+            nsend += peer_count[p];
+            nghost += hdr[0];
+        }
+        w[DDW_OVER] = over;
+        w[DDW_ERR] = err;
+        w[DDW_NSEND] = nsend;
+        w[DDW_NGHOST] = nghost;
     }
-    w[DDW_OVER] = over;
-    w[DDW_ERR] = err;                  // mine or a peer's: the same word on every rank
-    w[DDW_NSEND] = nsend;
-    w[DDW_NGHOST] = nghost;
-}
-
-// padded ghost messages -> the ghosts behind the owned atoms (recv_start: prefix of the receive counts, now known)
-template <typename real>
-__global__ void k_dd_unpack_ghost_rows_padded(int n, DdPlan plan, DdCaps rcaps, const unsigned char *__restrict__ recv,
-                                              real *__restrict__ x, emdee_lj_atom *__restrict__ atoms) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    int p = 0;
-    while (p + 1 < plan.npeers && k >= plan.recv_start[p + 1]) p++;
-    const GhostRow<real> r = reinterpret_cast<const GhostRow<real> *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)))[k - plan.recv_start[p]];
+    if (t >= rcaps.start[rcaps.npeers]) return;
+    const int p = dd_caps_peer(rcaps, t), slot = t - rcaps.start[p], cap = rcaps.start[p + 1] - rcaps.start[p];
+    const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
+    const int q = ghost_base + t;
+    // (a sender that overflowed packed no row at all: its count says more than its message holds -- nothing of it is kept)
+    const bool have = hdr[1] == 0 && slot < min(max(hdr[0], 0), cap);
+    if (have) {
+        const GhostRow<real> r = reinterpret_cast<const GhostRow<real> *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)))[slot];
+        if (EMDEE_BOUND(BS_DD_GHOST_UNPACK, slot, cap)) {
+            store_rec<real>(rec, te, q, r.x[0], r.x[1], r.x[2], r.hs, r.te);
+            // (a ghost in a cell that also holds owned atoms goes through the owner lane of the step kernel like they do -- no
+            // row, no force: with zero velocity it stays where the halo put it and never trips the rebuild trigger)
 #pragma unroll
-    for (int d = 0; d < 3; d++) x[3 * (size_t)k + d] = r.x[d];
-    emdee_lj_atom a;
-    a.half_sigma = r.hs; a.twice_sqrt_eps = r.te;
-    atoms[k] = a;
+            for (int d = 0; d < 3; d++) vel[d * pitch + q] = (real)0;
+            tag[q] = r.gid;
+        }
+    }
+    keep[q] = have ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------ in-process transport
@@ -485,7 +593,7 @@ __global__ void k_dd_unpack_step(int n, int n_owned, DdPlan plan, const int *__r
     int p = 0;
     while (p + 1 < plan.npeers && k >= plan.recv_start[p + 1]) p++;
     const real *in = reinterpret_cast<const real *>(buf + (size_t)(p + 1) * DD_HDR) + 3 * (size_t)k;
-    const int q = inv_perm[n_owned + k];
+    const int q = inv_perm[plan.ghost_id[p] + (k - plan.recv_start[p])];
     Rec<real> r = rec[q];
     r.x = in[0]; r.y = in[1]; r.z = in[2];
     rec[q] = r;

@@ -163,7 +163,7 @@ struct MdImpl : IMd {
         use_device(sys.ctx);
         EMDEE_REQUIRE(vel || n_owned == 0, EMDEE_ERR_INVALID, "velocities are NULL");
         n_ghost = ng;
-        sys.load_user(n_owned, ng, (const real *)pos, (const real *)vel, atoms, (const real *)inv_mass);
+        sys.load_user(n_owned, ng, (const real *)pos, (const real *)vel, atoms, (const real *)inv_mass, tags_user);
         since_build = 0;
         current_mask = 0;
         if (!defer_forces) {
@@ -174,10 +174,18 @@ struct MdImpl : IMd {
     }
     // emdee_dd_step: the rebuild in the middle of a run is followed by a fused step, which evaluates the forces itself
     bool defer_forces = false;
+    // decomposed domains: the global ids of the atoms handed to set_state (caller order, owned atoms and ghosts); they travel
+    // with the atoms from then on (NbSystem::tag) and order the atoms of a cell
+    const long long *tags_user = nullptr;
+    // an engine of an in-process decomposition runs on a stream of the library's own: the context its queries answer to
+    // (common.hpp FenceOut; NULL: the engine's context is the caller's)
+    const emdee_ctx *caller_ctx = nullptr;
     void get_state(void *pos, void *vel, void *frc, void *en, void *vir) override {
         use_device(sys.ctx);
         EMDEE_REQUIRE(sys.sorted, EMDEE_ERR_STATE, "md: no state loaded");
         if ((en || vir) && (current_mask & 6) != 6) forces(7, 0);
+        sys.ids_map();                                       // (scratch of the engine's own: before the fence)
+        FenceOut fence(caller_ctx, sys.stream());
         sys.unsort((real *)pos, (real *)vel, (real *)frc, (real *)en, (real *)vir);
         EMDEE_HIP_CHECK(hipGetLastError());
     }
@@ -297,6 +305,8 @@ struct MdImpl : IMd {
     }
     void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) override {
         use_device(sys.ctx);
+        sys.ids_map();
+        FenceOut fence(caller_ctx, sys.stream());
         sys.export_list(counts, neighbors, capacity);
     }
     void profile(bool enable) override {

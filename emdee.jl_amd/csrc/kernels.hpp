@@ -237,16 +237,22 @@ __device__ __forceinline__ void wave_run(int key, int &first, int &len) {
 
 // Radix-count pass of the counting sort: one digit = the cell id.
 // (typed boxes: the digit is cell * nt + species, so that a cell's atoms come out grouped by species)
+// (keep, optional: one byte per item -- an item whose byte is 0 is not part of the new state: a decomposed domain re-sorts
+// its own records with the leavers and the old ghosts struck out and the arrivals appended, NbSystem::resort_edit)
 template <typename real, class Src, class Spc = NoSpecies>
 __global__ void k_cell_assign(int n, Src src, GridP<real> g, int *__restrict__ cell_of, int *__restrict__ count, Spc spc = Spc(),
-                              int nt = 1) {
+                              int nt = 1, const unsigned char *__restrict__ keep = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;                                   // lanes past the end form their own run and add nothing
     if (i < n) {
-        real x, y, z;
-        src.get(i, x, y, z);
-        c = cell_id(g, x, y, z) * nt + spc.of(i);
-        cell_of[i] = c + g.one_based;
+        if (keep == nullptr || keep[i] != 0) {
+            real x, y, z;
+            src.get(i, x, y, z);
+            c = cell_id(g, x, y, z) * nt + spc.of(i);
+            cell_of[i] = c + g.one_based;
+        } else {
+            cell_of[i] = -1;
+        }
     }
     int first, len;
     wave_run(c, first, len);
@@ -269,8 +275,11 @@ static __global__ void k_cell_scatter(int n, const int *__restrict__ cell_of, in
 // The same for the engine's rebuilds, with each id's sort key (caller id) stored next to it: the ranking pass below then
 // reads its cell-mates' keys from consecutive addresses instead of one dependent gather per cell-mate (cells of side
 // >= r_list hold ~18 atoms: 0.22 -> 0.1 ms per rebuild at 10^7 atoms).
+// (tag, optional: 64-bit ids that travel with the atoms -- decomposed domains order a cell's atoms by the low word of the
+// GLOBAL id, which makes the cell order independent of the local numbering, i.e. of the history of migrations)
 static __global__ void k_cell_scatter_keyed(int n, const int *__restrict__ cell_of, const int *__restrict__ start,
-                                            int *__restrict__ fill, const int *__restrict__ key, int2 *__restrict__ tmp) {
+                                            int *__restrict__ fill, const int *__restrict__ key, int2 *__restrict__ tmp,
+                                            const long long *__restrict__ tag = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (i < n) ? cell_of[i] : -1;
     int first, len;
@@ -278,17 +287,24 @@ static __global__ void k_cell_scatter_keyed(int n, const int *__restrict__ cell_
     int base = 0;
     if (c >= 0 && lane_id() == first) base = start[c] + atomicAdd(&fill[c], len);
     base = __shfl(base, first);
-    if (c >= 0) tmp[base + (lane_id() - first)] = make_int2(i, key ? key[i] : i);
+    if (c >= 0) tmp[base + (lane_id() - first)] = make_int2(i, tag ? (int)tag[i] : (key ? key[i] : i));
 }
+// (n_dev, optional: the number of items that were scattered, as a device word -- a re-sort with struck-out items launches over
+// the upper bound; equal keys -- only the low words of two 64-bit tags can collide -- are ranked by the item index)
 static __global__ void k_cell_rankfix_keyed(int n, const int *__restrict__ cell_of, const int *__restrict__ start,
-                                            const int2 *__restrict__ tmp, int *__restrict__ order) {
+                                            const int2 *__restrict__ tmp, int *__restrict__ order,
+                                            const int *__restrict__ n_dev = nullptr) {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (q >= n) return;
     const int2 me = tmp[q];
     const int c = cell_of[me.x];
     const int s = start[c], e = start[c + 1];
     int rank = 0;
-    for (int r = s; r < e; r++) rank += (tmp[r].y < me.y) ? 1 : 0;
+    for (int r = s; r < e; r++) {
+        const int2 o = tmp[r];
+        rank += (o.y < me.y || (o.y == me.y && o.x < me.x)) ? 1 : 0;
+    }
     order[s + rank] = me.x;
 }
 
@@ -409,10 +425,12 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
                               const real *__restrict__ inv_mass, Rec<real> *__restrict__ rec, float *__restrict__ te,
                               real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
                               int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
-                              int *__restrict__ img, int nt = 1) {
+                              int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
+                              long long *__restrict__ tag_out = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int i = order[p];
+    if (tag_out) tag_out[p] = tag_in[i];
     real x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
     const int kx = wrap_into_box(x, g.lo[0], g.len[0], g.per[0]);
     const int ky = wrap_into_box(y, g.lo[1], g.len[1], g.per[1]);
@@ -432,7 +450,11 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
 }
 
 // Re-sort an already cell-ordered state (MD rebuild). order[p] = OLD slot of new slot p.
-template <typename real>
+// EDIT (NbSystem::resort_edit, a decomposed domain's rebuild in its own order): the old slots are the ids from now on
+// (perm[p] = o: atoms that stay keep no other name, arrivals and new ghosts sit behind the old state), the image counts
+// start afresh (the positions were wrapped by the ownership pass; an atom that changes owner takes no count along), only
+// the *n_dev items that were kept exist, and their number goes out with the words of the rebuild's one read-back.
+template <typename real, bool EDIT = false>
 __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *__restrict__ order,
                                 const int *__restrict__ cell_of, const Rec<real> *__restrict__ rec_in,
                                 const float *__restrict__ te_in, const real *__restrict__ v_in,
@@ -440,15 +462,21 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
                                 const int *__restrict__ img_in, Rec<real> *__restrict__ rec, float *__restrict__ te,
                                 real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
                                 int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
-                                int *__restrict__ img, int nt = 1) {
+                                int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
+                                long long *__restrict__ tag_out = nullptr, const int *__restrict__ n_dev = nullptr,
+                                int *__restrict__ n_out = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (EDIT) {
+        n = min(n, *n_dev);
+        if (p == 0 && n_out) *n_out = *n_dev;
+    }
     if (p >= n) return;
     int o = order[p];
     Rec<real> r = rec_in[o];
     float hs, tev;
     rec_params(rec_in, te_in, o, hs, tev);
-    int kx, ky, kz;
-    img_unpack(img_in[o], kx, ky, kz);
+    int kx = 0, ky = 0, kz = 0;
+    if (!EDIT) img_unpack(img_in[o], kx, ky, kz);
     kx += wrap_into_box(r.x, g.lo[0], g.len[0], g.per[0]);
     ky += wrap_into_box(r.y, g.lo[1], g.len[1], g.per[1]);
     kz += wrap_into_box(r.z, g.lo[2], g.len[2], g.per[2]);
@@ -459,7 +487,8 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
         for (int d = 0; d < 3; d++) v_out[d * pitch + p] = v_in[d * pitch + o];
     }
     if (im_out) im_out[p] = im_in[o];
-    int i = perm_in[o];
+    if (tag_out) tag_out[p] = tag_in[o];
+    int i = EDIT ? o : perm_in[o];
     perm[p] = i;
     inv_perm[i] = p;
     cell_sorted[p] = cell_of[o] / nt;
@@ -757,13 +786,14 @@ template <typename real>
 __global__ void k_langevin_noise(int n, int n_owned, size_t pitch, const int *__restrict__ perm,
                                  const long long *__restrict__ ids, const real *__restrict__ inv_mass,
                                  unsigned long long seed, unsigned long long step, double c2, double temperature,
-                                 real *__restrict__ noise) {
+                                 real *__restrict__ noise, const long long *__restrict__ tag = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int i = perm[p];
     if (i >= n_owned) return;
     double xi[3];
-    lgv_normals(seed, step, (unsigned long long)(ids ? ids[i] : (long long)i), xi);
+    // (tag: the ids that travel with the atoms in cell order -- decomposed domains; ids: a caller-order array)
+    lgv_normals(seed, step, (unsigned long long)(tag ? tag[p] : (ids ? ids[i] : (long long)i)), xi);
     const double amp = c2 * sqrt(temperature * (inv_mass ? (double)inv_mass[p] : 1.0));
     noise[p] = (real)(amp * xi[0]); noise[pitch + p] = (real)(amp * xi[1]); noise[2 * pitch + p] = (real)(amp * xi[2]);
 }
@@ -791,29 +821,49 @@ __global__ void k_kick(int n, int n_owned, size_t pitch, const int *__restrict__
 }
 
 // ------------------------------------------------------------------------------------ caller-order copies
+// One thread per cell-order slot p, written to the atom's id i = perm[p] -- or, when the ids have gaps (a decomposed domain
+// that re-sorted its own records: NbSystem::resort_edit), to the rank of that id among the ids in use, cmap[i]: owned atoms
+// first, then the ghosts, as every caller of these copies expects.  raw: the record's own coordinates, without the box
+// lengths the sorts removed (the ownership pass of a decomposition wraps them anyway).
 template <typename real>
 __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, const int *__restrict__ img,
-                         const int *__restrict__ inv_perm,
-                         const Rec<real> *__restrict__ rec, const real *__restrict__ vel, const real *__restrict__ frc,
-                         const real *__restrict__ en, const real *__restrict__ vir, real *__restrict__ pos_out,
+                         const int *__restrict__ perm, const int *__restrict__ cmap,
+                         const Rec<real> *__restrict__ rec, const float *__restrict__ te, const real *__restrict__ vel,
+                         const real *__restrict__ frc,
+                         const real *__restrict__ en, const real *__restrict__ vir, const long long *__restrict__ tag,
+                         real *__restrict__ pos_out,
                          real *__restrict__ vel_out, real *__restrict__ frc_out, real *__restrict__ en_out,
-                         real *__restrict__ vir_out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_total) return;
-    int p = inv_perm[i];
+                         real *__restrict__ vir_out, emdee_lj_atom *__restrict__ atoms_out, long long *__restrict__ tag_out,
+                         int raw) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_total) return;
+    const int id = perm[p];
+    const int i = cmap ? cmap[id] : id;
     if (pos_out) {
         Rec<real> r = rec[p];
-        int kx, ky, kz;
-        img_unpack(img[p], kx, ky, kz);   // back to the caller's (unwrapped) image
+        int kx = 0, ky = 0, kz = 0;
+        if (!raw) img_unpack(img[p], kx, ky, kz);   // back to the caller's (unwrapped) image
         pos_out[3 * (size_t)i] = r.x + (real)kx * g.len[0];
         pos_out[3 * (size_t)i + 1] = r.y + (real)ky * g.len[1];
         pos_out[3 * (size_t)i + 2] = r.z + (real)kz * g.len[2];
     }
-    if (i >= n_owned) return;
+    if (atoms_out) {
+        emdee_lj_atom a;
+        rec_params(rec, te, p, a.half_sigma, a.twice_sqrt_eps);
+        atoms_out[i] = a;
+    }
+    if (tag_out) tag_out[i] = tag[p];
+    if (id >= n_owned) return;
     if (vel_out) for (int d = 0; d < 3; d++) vel_out[3 * (size_t)i + d] = vel[d * pitch + p];
     if (frc_out) for (int d = 0; d < 3; d++) frc_out[3 * (size_t)i + d] = frc[d * pitch + p];
     if (en_out) en_out[i] = en[p];
     if (vir_out) vir_out[i] = vir[p];
+}
+
+// ids in use -> their ranks (cmap): live[id] = 1 for every id some slot carries, then an exclusive scan of live[]
+static __global__ void k_mark_live(int n, const int *__restrict__ perm, int *__restrict__ live) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) live[perm[p]] = 1;
 }
 
 // sets *flag if any LJAtom differs (bitwise) from the first one
@@ -866,14 +916,18 @@ __global__ void k_unpack_ghosts(int n, int first_id, const int *__restrict__ inv
 
 // neighbour rows of the direct (int32, cell-order slot) list as caller ids
 static __global__ void k_export_rows(int n, int n_owned, const int *__restrict__ perm, const int *__restrict__ nbr, int stride,
-                                     const int *__restrict__ cnt, int *__restrict__ counts, int *__restrict__ out, int capacity) {
+                                     const int *__restrict__ cnt, int *__restrict__ counts, int *__restrict__ out, int capacity,
+                                     const int *__restrict__ cmap = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const int i = perm[p];
-    if (i >= n_owned) return;
+    if (perm[p] >= n_owned) return;
+    const int i = cmap ? cmap[perm[p]] : perm[p];
     const int m = cnt[p];
     counts[i] = m;
-    for (int e = 0; e < m && e < capacity; e++) out[(size_t)i * capacity + e] = perm[nbr[(size_t)p * stride + e]];
+    for (int e = 0; e < m && e < capacity; e++) {
+        const int j = perm[nbr[(size_t)p * stride + e]];
+        out[(size_t)i * capacity + e] = cmap ? cmap[j] : j;
+    }
 }
 
 // ------------------------------------------------------------------------------------ reductions

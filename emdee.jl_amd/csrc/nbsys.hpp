@@ -145,6 +145,21 @@ struct NbSystem {
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
     DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, count, fill, nbr, cnt, flags, img, img2;
     DevBuf<int2> tmp2;                    // {id, sort key} in arrival order inside each cell (bin)
+    // 64-bit ids that travel with the atoms through every sort (decomposed domains: the GLOBAL ids, owned atoms and ghosts).
+    // With them the order inside a cell is by the low word of the tag, not by the local id: the cell order -- and with it the
+    // order of every neighbour row and force sum -- no longer depends on how a domain numbers its atoms, i.e. on the history
+    // of migrations or on the path a rebuild took (counted, count-free, in the engine's own order).
+    DevBuf<long long> tag, tag2;
+    bool use_tags = false;
+    size_t cap_hint = 0;                  // reserve() sizes the per-atom arrays (and the plane pitch) for at least this many slots
+    size_t capacity = 0;                  // ... what they hold
+    bool has_ghosts = false;
+    // ids: perm[p] < n_owned <=> owned.  After resort_edit the ids in use have gaps (id_space > n_total); callers that want
+    // dense caller-order arrays get them through ids_map() (rank of every id in use: owned first, then ghosts)
+    int id_space = 0;
+    bool id_gaps = false;
+    DevBuf<int> cmap;
+    bool cmap_valid = false;
     // typed boxes (two species): sort digit = cell * nt + species; count[] then holds the per-(cell, species) starts and
     // cstart[] the per-cell ones every untyped consumer reads
     SpeciesTable species{1, {0, 0, 0, 0}};
@@ -246,24 +261,28 @@ struct NbSystem {
 
     void reserve(int n, bool velocities, bool masses) {
         n_total = n;
-        pitch = ((size_t)n + 63) / 64 * 64 + 64;
+        const size_t m = std::max((size_t)n, cap_hint);
+        capacity = m;
+        pitch = (m + 63) / 64 * 64 + 64;
         with_vel = velocities;
         with_mass = masses;
-        rec.ensure(n + 1); rec2.ensure(n + 1);
-        if (sizeof(real) == 4) { te.ensure(n + 1); te2.ensure(n + 1); }
+        rec.ensure(m + 1); rec2.ensure(m + 1);
+        if (sizeof(real) == 4) { te.ensure(m + 1); te2.ensure(m + 1); }
         frc.ensure(3 * pitch); en.ensure(pitch); vir.ensure(pitch); xb.ensure(3 * pitch);
         if (velocities) { vel.ensure(3 * pitch); vel2.ensure(3 * pitch); }
         if (masses) { im.ensure(pitch); im2.ensure(pitch); }
-        perm.ensure(n + 1); perm2.ensure(n + 1); inv_perm.ensure(n + 1); img.ensure(n + 1); img2.ensure(n + 1);
-        cell_of.ensure(n + 1); cell_sorted.ensure(n + 1); order.ensure(n + 1); cnt.ensure(n + 1);
+        perm.ensure(m + 1); perm2.ensure(m + 1); inv_perm.ensure(m + 1); img.ensure(m + 1); img2.ensure(m + 1);
+        cell_of.ensure(m + 1); cell_sorted.ensure(m + 1); order.ensure(m + 1); cnt.ensure(m + 1);
+        if (use_tags) { tag.ensure(m + 1); tag2.ensure(m + 1); }
         if (flags.ensure(16)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 16 * sizeof(int), stream()));
         partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
     }
 
     // ---------------------------------------------------------------- binning
+    // n_items / tagkey / keep: see resort_edit (items struck out by keep[] take no part; the number that do is count[nbins])
     template <class Src, class Spc>
-    void bin(Src src, const int *key, Spc spc) {
-        const int n = n_total;
+    void bin(Src src, const int *key, Spc spc, int n_items = -1, const long long *tagkey = nullptr, const unsigned char *keep = nullptr) {
+        const int n = n_items >= 0 ? n_items : n_total;
         const int dm = digits();
         const size_t nbins = ncell * (size_t)dm;
         count.ensure(nbins + 2); fill.ensure(nbins + 2);
@@ -275,13 +294,13 @@ struct NbSystem {
         }
         if (n == 0) return;
         hipLaunchKernelGGL((k_cell_assign<real, Src, Spc>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
-                           cell_of.ptr, count.ptr, spc, dm);
+                           cell_of.ptr, count.ptr, spc, dm, keep);
         scanner.run(count.ptr, nbins + 1, stream());   // count[] becomes the start of every (cell, species / sub-bin) block
-        tmp2.ensure(n + 1);
+        tmp2.ensure(std::max((size_t)n, capacity) + 1);
         hipLaunchKernelGGL(k_cell_scatter_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
-                           fill.ptr, key, tmp2.ptr);
+                           fill.ptr, key, tmp2.ptr, tagkey);
         hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
-                           tmp2.ptr, order.ptr);
+                           tmp2.ptr, order.ptr, keep ? count.ptr + nbins : nullptr);
         if (dm > 1)
             hipLaunchKernelGGL(k_cell_starts, dim3(blocks_for(ncell + 1, 256)), dim3(256), 0, stream(), (int)ncell, dm, count.ptr, cstart.ptr);
     }
@@ -298,37 +317,41 @@ struct NbSystem {
     // sub-bins only where the round-robin two-phase build can use them: the tiled path of an untyped box
     void choose_subbins() { nsub = (subbins_enabled && path == PATH_BRICK && nt == 1 && n_total > 0) ? 4 : 1; }
     template <class Src>
-    void bin_untyped(Src src, const int *key) {
-        if (nsub > 1) bin(src, key, XSubBin<real, Src>{src, grid.lo[0], grid.len[0], grid.M[0], grid.per[0], nsub});
-        else bin(src, key, NoSpecies{});
+    void bin_untyped(Src src, const int *key, int n_items = -1, const long long *tagkey = nullptr, const unsigned char *keep = nullptr) {
+        if (nsub > 1) bin(src, key, XSubBin<real, Src>{src, grid.lo[0], grid.len[0], grid.M[0], grid.per[0], nsub}, n_items, tagkey, keep);
+        else bin(src, key, NoSpecies{}, n_items, tagkey, keep);
     }
     const int *start() const { return digits() > 1 ? cstart.ptr : count.ptr; }   // first slot of every cell
     const int *tstart() const { return count.ptr; }                        // ... of every (cell, species) block (typed boxes)
 
     // caller-order arrays -> cell-ordered state (+ list)
+    // (tags_user, optional: 64-bit ids in caller order, owned atoms and ghosts -- see `tag`)
     void load_user(int n_own, int n_ghost, const real *pos, const real *velocities, const emdee_lj_atom *atoms,
-                   const real *inv_mass) {
+                   const real *inv_mass, const long long *tags_user = nullptr) {
         EMDEE_REQUIRE(n_own >= 0 && n_ghost >= 0, EMDEE_ERR_INVALID, "negative atom count");
         EMDEE_REQUIRE((int64_t)n_own + n_ghost < (int64_t)1 << 31, EMDEE_ERR_INVALID, "too many atoms");
         EMDEE_REQUIRE(n_own + n_ghost == 0 || (pos && atoms), EMDEE_ERR_INVALID, "positions/atoms are NULL");
         Timed t(this, T_REBUILD);
         n_owned = n_own;
+        has_ghosts = n_ghost > 0;
+        id_space = n_own + n_ghost; id_gaps = false; cmap_valid = false;
         lgv_ids = nullptr;                                   // caller-order array of the previous state
+        use_tags = tags_user != nullptr;
         reserve(n_own + n_ghost, velocities != nullptr || with_vel, inv_mass != nullptr);
         detect_uniform_atoms(atoms);
         configure_grid();
         const int n = n_total;
         choose_subbins();
-        if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms});
-        else bin_untyped(UserPos<real>{pos}, nullptr);
+        if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms}, -1, use_tags ? tags_user : nullptr);
+        else bin_untyped(UserPos<real>{pos}, nullptr, -1, use_tags ? tags_user : nullptr);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img.ptr, digits());
+                               cell_sorted.ptr, img.ptr, digits(), use_tags ? tags_user : nullptr, use_tags ? tag.ptr : nullptr);
         // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
         // from the start; their coordinates are refreshed by every halo unpack
-        if (n > n_owned)
+        if (has_ghosts)
             hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned,
                                perm.ptr, rec.ptr, rec2.ptr);
         sorted = true;
@@ -342,24 +365,107 @@ struct NbSystem {
         const int n = n_total;
         configure_grid();
         choose_subbins();
-        if (nt > 1) bin(RecPos<real>{rec.ptr}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr});
-        else bin_untyped(RecPos<real>{rec.ptr}, perm.ptr);
+        const long long *tk = use_tags ? tag.ptr : nullptr;
+        if (nt > 1) bin(RecPos<real>{rec.ptr}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr}, -1, tk);
+        else bin_untyped(RecPos<real>{rec.ptr}, perm.ptr, -1, tk);
         if (n > 0)
-            hipLaunchKernelGGL((k_gather_sorted<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
+            hipLaunchKernelGGL((k_gather_sorted<real, false>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
                                with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img2.ptr, digits());
+                               cell_sorted.ptr, img2.ptr, digits(), tk, use_tags ? tag2.ptr : nullptr);
+        swap_sorted_buffers();
+        build_list();
+    }
+    void swap_sorted_buffers() {
         rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2);
         if (with_vel) vel.swap(vel2);
         if (with_mass) im.swap(im2);
-        build_list();
+        if (use_tags) tag.swap(tag2);
+    }
+
+    // ---------------------------------------------------------------- a decomposed domain's rebuild in its own order (dd.hpp)
+    // The state is re-sorted from its OWN records -- no caller-order copy, no assembly of new caller arrays, no load:
+    //  * keep[q] == 0 strikes slot q out (atoms that left for a neighbour, the old ghosts, the unused rows of padded messages);
+    //  * the arrivals and the new ghosts have been written behind the old state, slots [n_total, n_items), by the caller --
+    //    records (both LJAtom fields), velocity planes, tags;
+    //  * the OLD slot q is an atom's id from now on: ids >= own_limit are ghosts (the ids in use have gaps: ids_map()).
+    // How many atoms that leaves is a device word (*n_live_dev) until the build's read-back, which carries the caller's words
+    // (`extra`: counts and overflow words of the messages) along: ONE blocking read-back for the whole rebuild.  The kernels in
+    // between run over n_items.  The old state stays intact in the spare buffers until commit_edit(): when a message of the
+    // rebuild turns out to have overflowed, rollback_edit() puts it back and the caller redoes the rebuild with counts.
+    struct EditWords {
+        const int *dev = nullptr;
+        int n = 0;
+        int32_t *host = nullptr;
+    };
+    bool in_edit = false, edit_abort = false;
+    EditWords edit_extra{};
+    int edit_n_plan = 0;
+    struct EditSaved { int n_total, n_owned, id_space; bool id_gaps, has_ghosts, has_list; } edit_saved{};
+    bool edit_fits(int n_items) const { return sorted && use_tags && with_vel && !with_mass && (size_t)n_items <= capacity; }
+    bool edit_extra_read = false;
+    bool resort_edit(int n_items, const unsigned char *keep, int own_limit, bool ghosts, int *n_live_dev, EditWords extra) {
+        EMDEE_REQUIRE(edit_fits(n_items), EMDEE_ERR_STATE, "resort_edit: the state does not hold %d slots", n_items);
+        Timed t(this, T_REBUILD);
+        edit_saved = EditSaved{n_total, n_owned, id_space, id_gaps, has_ghosts, has_list};
+        configure_grid();
+        choose_subbins();
+        if (nt > 1) bin(RecPos<real>{rec.ptr}, nullptr, RecSpecies<real>{species, rec.ptr, te.ptr}, n_items, tag.ptr, keep);
+        else bin_untyped(RecPos<real>{rec.ptr}, nullptr, n_items, tag.ptr, keep);
+        const size_t nbins = ncell * (size_t)digits();
+        hipLaunchKernelGGL((k_gather_sorted<real, true>), dim3(blocks_for(n_items, 256)), dim3(256), 0, stream(), n_items, pitch, grid,
+                           order.ptr, cell_of.ptr, rec.ptr, te.ptr, vel.ptr, (const real *)nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr,
+                           xb.ptr, vel2.ptr, (real *)nullptr, perm2.ptr, inv_perm.ptr, cell_sorted.ptr, img2.ptr, digits(), tag.ptr,
+                           tag2.ptr, count.ptr + nbins, n_live_dev);
+        swap_sorted_buffers();
+        edit_n_plan = n_total;
+        n_total = n_items;                                  // an upper bound until commit_edit()
+        n_owned = own_limit;
+        has_ghosts = ghosts;
+        id_space = n_items; id_gaps = true; cmap_valid = false;
+        in_edit = true; edit_abort = false; edit_extra = extra; edit_extra_read = false;
+        struct Leave { bool &f; ~Leave() { f = false; } } leave{in_edit};
+        // (an engine on the direct kernels, or without atoms so far: they count atoms on the host -- the re-sorted state is
+        // complete, the caller reads the counts and loads the engine from it)
+        if (path == PATH_BRICK && plan_valid && edit_saved.n_total > 0) build_list();
+        else edit_abort = true;
+        if (edit_abort && !edit_extra_read && extra.n > 0) read_back_words(ctx, stream(), extra.dev, extra.n, extra.host);
+        return !edit_abort;
+    }
+    void commit_edit(int n_live) {
+        EMDEE_REQUIRE(n_live >= 0 && n_live <= n_total, EMDEE_ERR_STATE, "resort_edit: %d atoms in %d slots", n_live, n_total);
+        n_total = n_live;
+        // ghosts are never written by the step kernel: both position buffers carry their records from the start (only now:
+        // until here the spare buffer held the state to roll back to)
+        if (has_ghosts && n_total > 0)
+            hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
+                               perm.ptr, rec.ptr, rec2.ptr);
+    }
+    void rollback_edit() {
+        swap_sorted_buffers();
+        n_total = edit_saved.n_total; n_owned = edit_saved.n_owned; id_space = edit_saved.id_space;
+        id_gaps = edit_saved.id_gaps; has_ghosts = edit_saved.has_ghosts;
+        cmap_valid = false;
+        has_list = false; plan_valid = false; btab_valid = false;   // (inv_perm, xb, the cell tables and the list are the discarded sort's)
+    }
+    // rank of every id in use among the ids in use (NULL: the ids have no gaps)
+    const int *ids_map() {
+        if (!id_gaps) return nullptr;
+        if (!cmap_valid) {
+            cmap.ensure((size_t)id_space + 2);
+            EMDEE_HIP_CHECK(hipMemsetAsync(cmap.ptr, 0, ((size_t)id_space + 1) * sizeof(int), stream()));
+            if (n_total > 0) hipLaunchKernelGGL(k_mark_live, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, perm.ptr, cmap.ptr);
+            scanner.run(cmap.ptr, (size_t)id_space + 1, stream());
+            cmap_valid = true;
+        }
+        return cmap.ptr;
     }
 
     // ---------------------------------------------------------------- brick plumbing
     BrickArgs<real> brick_args(int phase = 0) {
         BrickArgs<real> a{};
-        a.n = n_total; a.n_owned = n_owned;
+        a.n = n_total; a.n_owned = n_owned; a.any_ghosts = has_ghosts ? 1 : 0;
         a.rec = rec.ptr; a.te = te.ptr; a.perm = perm.ptr; a.start = start();
         a.g = grid; a.bg = bgrid; a.tile_cap = tile_cap; a.own_cap = own_cap;
         a.nbr = nbr16.ptr; a.stride = stride; a.cnt = cnt.ptr; a.flags = flags.ptr;
@@ -686,7 +792,7 @@ struct NbSystem {
         plan_valid = brick_active;
         plan_uniform = uniform_atoms;
         plan_nt = nt;
-        plan_n = n;
+        plan_n = in_edit ? edit_n_plan : n;
         for (int d = 0; d < 3; d++) plan_M[d] = grid.M[d];
     }
     bool plan_uniform = false;
@@ -711,8 +817,10 @@ struct NbSystem {
         // The plan of the previous build of this state (variant, capacities, build kernel) is kept when the cell grid is the
         // same: the populations barely change between rebuilds, the capacities carry headroom, and the maxima of the new
         // populations come back with the build's overflow words -- ONE blocking read-back per rebuild instead of two.
+        // (inside resort_edit n is an upper bound: the plan is compared with the number of atoms before the edit)
+        const int np = in_edit ? edit_n_plan : n;
         bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && !std::getenv("EMDEE_NO_BRICK_TABLES") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
-                    plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= n + n / 8 && n <= plan_n + plan_n / 8 &&
+                    plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= np + np / 8 && np <= plan_n + plan_n / 8 &&
                     plan_uniform == uniform_atoms && plan_nt == nt;
         if (kept) {
             plan_geometry();
@@ -726,11 +834,14 @@ struct NbSystem {
         } else {
             make_plan();
         }
+        // (a state with a capacity hint -- decomposed domains -- sizes the list for it: no reallocation while atoms come and go)
+        const size_t rows = std::max<size_t>((size_t)std::max(n, 1), cap_hint ? capacity : 0);
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
+            if (in_edit && !brick_active) { edit_abort = true; return; }   // (the direct kernels count atoms on the host: the caller reloads)
             EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 5 * sizeof(int), stream()));
             if (brick_active) {
-                nbr16.ensure((size_t)std::max(n, 1) * stride);
+                nbr16.ensure(rows * stride);
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
                     if constexpr (typed_variant<V>()) {
@@ -810,7 +921,7 @@ struct NbSystem {
                                        brick_args());
                 });
             } else {
-                nbr.ensure((size_t)std::max(n, 1) * stride);
+                nbr.ensure(rows * stride);
                 if (n > 0)
                     hipLaunchKernelGGL((k_nbr_build<real>), dim3(blocks_for((size_t)n * WAVE, NBR_BLOCK)), dim3(NBR_BLOCK),
                                        0, stream(), n, n_owned, view(), perm.ptr, cell_sorted.ptr, start(), grid,
@@ -818,7 +929,12 @@ struct NbSystem {
             }
             // a build is rare (every ~7 steps): one blocking read-back -- the overflow words and, under a kept plan, the
             // population maxima it has to hold for
-            read_back_words(ctx, stream(), flags.ptr, 9, ctx->host_flags);
+            if (in_edit && edit_extra.n > 0) {
+                read_back_words(ctx, stream(), flags.ptr, 9, ctx->host_flags, edit_extra.dev, edit_extra.n, edit_extra.host);
+                edit_extra_read = true;
+            } else {
+                read_back_words(ctx, stream(), flags.ptr, 9, ctx->host_flags);
+            }
             if (kept && (!plan_holds(ctx->host_flags + 6) || ctx->host_flags[2] != 0)) {
                 // the populations outgrew the kept plan (the kernels skipped the bricks concerned): plan afresh and build again
                 kept = false;
@@ -955,6 +1071,7 @@ struct NbSystem {
     double lgv_gamma = 0.0, lgv_T = 0.0, lgv_c1 = 1.0;
     unsigned long long lgv_seed = 0, lgv_step = 0;
     const long long *lgv_ids = nullptr;    // caller-order ids for the noise counters (NULL: the caller index)
+    bool lgv_by_tag = false;               // ... or the tags that travel with the atoms (decomposed domains)
     void set_langevin(double gamma, double temperature, unsigned long long seed, unsigned long long first_step,
                       const long long *ids) {
         EMDEE_REQUIRE(std::isfinite(gamma) && std::isfinite(temperature) && temperature >= 0.0, EMDEE_ERR_INVALID,
@@ -970,7 +1087,7 @@ struct NbSystem {
         const double c2 = std::sqrt(1.0 - lgv_c1 * lgv_c1);
         hipLaunchKernelGGL((k_langevin_noise<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total,
                            n_owned, pitch, perm.ptr, lgv_ids, with_mass ? im.ptr : nullptr, lgv_seed, lgv_step, c2, lgv_T,
-                           noise.ptr);
+                           noise.ptr, (use_tags && lgv_by_tag) ? tag.ptr : nullptr);
     }
 
     // One inner velocity-Verlet step as a single kernel: f(x_k), v += c f/m, x_{k+1} = x_k + dt v written to
@@ -995,7 +1112,7 @@ struct NbSystem {
         }
         if (phase != 1 && lgv_on) lgv_step++;
         if (phase != 1) {
-            if (carry_ghosts && n_total > n_owned)
+            if (carry_ghosts && has_ghosts)
                 hipLaunchKernelGGL((k_copy_ghost_records<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(),
                                    n_total, n_owned, perm.ptr, rec.ptr, rec2.ptr);
             swap_step_buffers();
@@ -1016,7 +1133,7 @@ struct NbSystem {
     int fused_steps_run_ahead(double c, double dt, int want, bool *stale) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         *stale = false;
-        if (!brick_active || n_total == 0 || n_total > n_owned) return 0;
+        if (!brick_active || n_total == 0 || has_ghosts) return 0;
         const int B = std::max(1, std::min(want, run_ahead));
         int *words = flags.ptr + 9;                          // flags[9 .. 9 + RUN_AHEAD)
         EMDEE_HIP_CHECK(hipMemsetAsync(words, 0, B * sizeof(int), stream()));
@@ -1149,6 +1266,7 @@ struct NbSystem {
         EMDEE_REQUIRE(has_list, EMDEE_ERR_STATE, "no neighbour list");
         EMDEE_REQUIRE(counts && out && capacity > 0, EMDEE_ERR_INVALID, "export_list: bad arguments");
         if (n_total == 0) return;
+        const int *map = ids_map();
         if (brick_active) {
             with_brick_variant(variant, [&](auto v) {
                 using V = decltype(v);
@@ -1157,7 +1275,7 @@ struct NbSystem {
                         auto tk = k_typed_export<real, typename V::Shape, V::THREADS, V::G>;
                         using TTab = TypedTables<typename V::Shape, V::THREADS>;
                         const size_t tlds = TTab::bytes(0);
-                        hipLaunchKernelGGL(tk, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), tlds, stream(), brick_args(), counts, out, capacity);
+                        hipLaunchKernelGGL(tk, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), tlds, stream(), brick_args(), counts, out, capacity, map);
                         return;
                     }
                 }
@@ -1165,22 +1283,27 @@ struct NbSystem {
                 using BT = BrickTables<typename V::Shape, V::THREADS>;
                 const size_t lds = BT::bytes(0);
                 hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds, stream(), brick_args(), counts, out,
-                                   capacity);
+                                   capacity, map);
             });
         } else {
             hipLaunchKernelGGL(k_export_rows, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned, perm.ptr, nbr.ptr,
-                               stride, cnt.ptr, counts, out, capacity);
+                               stride, cnt.ptr, counts, out, capacity, map);
         }
         EMDEE_HIP_CHECK(hipGetLastError());
     }
 
     // ---------------------------------------------------------------- caller-order copies
-    void unsort(real *pos, real *velocities, real *forces, real *energies, real *virials) {
+    // (dense caller order: owned atoms first, then the ghosts -- through ids_map() when the ids have gaps; atoms_out / tags_out
+    // / raw: what a decomposition needs to go back to caller-order arrays, dd.hpp)
+    void unsort(real *pos, real *velocities, real *forces, real *energies, real *virials, emdee_lj_atom *atoms_out = nullptr,
+                long long *tags_out = nullptr, bool raw = false) {
         if (n_total == 0) return;
         EMDEE_REQUIRE(!velocities || with_vel, EMDEE_ERR_STATE, "no velocities loaded");
+        EMDEE_REQUIRE(!tags_out || use_tags, EMDEE_ERR_STATE, "no tags loaded");
+        const int *map = ids_map();
         hipLaunchKernelGGL((k_unsort<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_owned, n_total, pitch,
-                           grid, img.ptr, inv_perm.ptr, rec.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr,
-                           pos, velocities, forces, energies, virials);
+                           grid, img.ptr, perm.ptr, map, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr,
+                           use_tags ? tag.ptr : nullptr, pos, velocities, forces, energies, virials, atoms_out, tags_out, raw ? 1 : 0);
     }
 
     // operator path: does the cached list still cover these caller positions?

@@ -127,7 +127,7 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
     // Decomposed runs: an own (species, cell) block that holds nothing but ghosts takes no part in the own-atom loops (as in
     // brick.hpp): bit 8 + species of the cell's shift word, set once the plain words are in place
     int ghosts_only = 0;
-    if (COMPUTE && a.n_owned < a.n && tid < NTT && my_cnt > 0) {
+    if (COMPUTE && a.any_ghosts && tid < NTT && my_cnt > 0) {
         const int tc = tid % NTC, tx = tc % TX, ty = (tc / TX) % TY, tz = tc / (TX * TY);
         if (tx >= 1 && tx <= BX && ty >= 1 && ty <= BY && tz >= 1 && tz <= BZ) {
             int owned = 0;
@@ -753,7 +753,8 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
 
 // verification accessor: the neighbour rows as CALLER ids, species-0 neighbours first
 template <typename real, class Shape, int THREADS, int G>
-__global__ __launch_bounds__(THREADS) void k_typed_export(BrickArgs<real> a, int *__restrict__ counts, int *__restrict__ out, int capacity) {
+__global__ __launch_bounds__(THREADS) void k_typed_export(BrickArgs<real> a, int *__restrict__ counts, int *__restrict__ out, int capacity,
+                                                          const int *__restrict__ cmap = nullptr) {
     constexpr int BLK = EPL * G, NTT = TNT * Shape::NTC;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     TypedTables<Shape, THREADS> T;
@@ -763,8 +764,8 @@ __global__ __launch_bounds__(THREADS) void k_typed_export(BrickArgs<real> a, int
     for (int o = threadIdx.x; o < n_own; o += THREADS) {
         int ti, p;
         typed_locate(T, o, ti, p);
-        const int i = a.perm[p];
-        if (i >= a.n_owned) continue;
+        if (a.perm[p] >= a.n_owned) continue;
+        const int i = cmap ? cmap[a.perm[p]] : a.perm[p];
         const int m = a.cnt[p], n0 = m & 0xffff, n1 = (int)((unsigned)m >> 16), S1 = (n0 + BLK - 1) / BLK * BLK;
         counts[i] = n0 + n1;
         const unsigned short *row = a.nbr + (size_t)p * a.stride;
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(THREADS) void k_typed_export(BrickArgs<real> a, int
                 const int mid = (lo + hi) >> 1;
                 if (T.off[mid] <= sl) lo = mid; else hi = mid;
             }
-            out[(size_t)i * capacity + e] = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+            const int j = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+            out[(size_t)i * capacity + e] = cmap ? cmap[j] : j;
         }
     }
 }

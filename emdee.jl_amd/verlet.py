@@ -108,15 +108,9 @@ class VelocityVerlet:
                    forces=mk(n, 3) if forces else None, energies=mk(n, 0) if energies else None,
                    virials=mk(n, 0) if virials else None)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        self._fence()
         _lib.call("emdee_md_get_state", self._handle, p(out["positions"]), p(out["velocities"]), p(out["forces"]),
                   p(out["energies"]), p(out["virials"]))
-        self._fence()
         return out
-
-    def _fence(self):
-        """Between torch's work on the arrays of a query and the library's: nothing to do while the engine runs on torch's
-        own stream (dd.py's engine views, whose engines run on streams of the library, synchronise the device here)."""
 
     def totals(self):
         """(potential energy, kinetic energy, virial sum) over owned atoms; fp64 reduction (blocking)."""
@@ -150,9 +144,7 @@ class VelocityVerlet:
         cap = max(self.nbr_stats()["capacity"], 1)
         counts = torch.zeros(self.n_owned, dtype=torch.int32, device=self.device)
         nb = torch.full((self.n_owned, cap), -1, dtype=torch.int32, device=self.device)
-        self._fence()
         _lib.call("emdee_md_nbr_list", self._handle, C.c_void_p(counts.data_ptr()), C.c_void_p(nb.data_ptr()), cap)
-        self._fence()
         return counts, nb
 
     def profile_(self, enable=True):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 5, GPU call A: the rebuild in the engines' own order -- decomposition tests, then the one-domain overhead probe
+# (whole ownership path) against the round-4 library on the same box, and the kernel timeline of one rebuild
+O=gpurun_out/r05a; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_gpu_dd.py -x -q --timeout 600 > $O/pytest_dd.log 2>&1; rc=$?; echo "pytest dd rc=$rc"; tail -15 $O/pytest_dd.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+R04=$PWD/emdee.jl_amd/variants/libemdee_hip_r04.so
+for lib in new r04; do
+  for form in "lockstep:A=1" "inorder:EMDEE_DD_OVERLAP=0"; do
+    name=${form%%:*}; envs=${form#*:}
+    if [ $lib = r04 ]; then export EMDEE_HIP_LIB=$R04; else unset EMDEE_HIP_LIB; fi
+    env $envs EMDEE_DD_NO_SHORTCUT=1 timeout -k 10 200 python profiles/dd_one_domain_overhead.py 68 dd > $O/one_domain_full_${name}_$lib.txt 2>&1 || exit 1
+    echo "full_${name}_$lib $(grep atoms $O/one_domain_full_${name}_$lib.txt)"
+  done
+done
+unset EMDEE_HIP_LIB
+timeout -k 10 200 python profiles/dd_one_domain_overhead.py 68 plain > $O/one_domain_plain.txt 2>&1; grep atoms $O/one_domain_plain.txt
+timeout -k 10 300 bash profiles/dd_rebuild_timeline.sh 68 $O/ddtl > $O/ddtl.log 2>&1; tail -60 $O/ddtl.log
