@@ -210,7 +210,7 @@ struct Domain {
     DevBuf<long long> gid, gid2;
     DevBuf<unsigned> mask, gmask;
     DevBuf<unsigned char> keep;                    // rebuild in the engine's order: slots that make it into the new state
-    DevBuf<int> counts, counts2, ids, bins, codes, small, small2;   // small: bin_start[33] | cnt_send[27] | cnt_recv[27] | err[1]
+    DevBuf<int> counts, counts2, ids, bins, codes, small;   // small: bin_start[33] | cnt_send[27] | cnt_recv[27] | err[1]
     DevBuf<unsigned char> sendbuf, recvbuf;
     DevBuf<int> words;
     DevBuf<double> red;
@@ -225,6 +225,7 @@ struct Domain {
     DdPlan plan{};
     Xfer xf{};
     int since_build = 0;
+    bool words_clear = false;            // the guard words were cleared by the rebuild that has just run
 
     int *V(int j) { return words.ptr + j; }
     int *G(int j) { return words.ptr + (DD_MAX_BATCH + 2) + j; }
@@ -640,6 +641,7 @@ struct DdImpl : IDd {
             ~Wall() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); n++; }
         } wall{stat_rebuild_wall_ms, stat_rebuild_calls};
         join_halo();
+        for (auto &pd : dom) pd->words_clear = false;
         if (world == 1 && from_engines && !no_shortcut) {
             // one domain, no cut: nobody to hand atoms to and no ghosts -- the engine's own re-sort (same list, same forces,
             // none of the ownership passes)
@@ -821,7 +823,7 @@ struct DdImpl : IDd {
         const size_t pad_r = std::max(dd_pad_total(d.mig_caps, sizeof(MigRow<real>)), dd_pad_total(d.gr_caps, sizeof(GhostRow<real>)));
         d.sendbuf.ensure(std::max(dd_msg_begin(d.plan.send_start, np, w), pad_s) + 64);
         d.recvbuf.ensure(std::max(dd_msg_begin(d.plan.recv_start, np, w), pad_r) + 64);
-        EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+        // (the guard words are cleared by whoever steps next: emdee_dd_step at its start, step_after_rebuild)
     }
 
     // A rebuild in the engines' own order (dd_kernels.hpp): two padded exchanges, device-side counts throughout, the engine's
@@ -868,29 +870,28 @@ struct DdImpl : IDd {
             d.mask.ensure((size_t)e.q_arr + 1);
             d.gmask.ensure((size_t)e.q_arr + (size_t)e.nblk_arr * PART_BLOCK + 1);
             d.w.ensure(DDW_COUNT);
-            d.small2.ensure(96);
             d.counts.ensure((size_t)nb1 * e.nblk1 + 2);
             d.counts2.ensure((size_t)nb2 * e.nblk_g + 2);
             d.ids.ensure((size_t)std::max(e.mig + PART_BLOCK, d.gs_caps.start[np]) + 1);
             d.bins.ensure((size_t)d.gs_caps.start[np] + 1);
             d.codes.ensure((size_t)d.gs_caps.start[np] + 1);
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.small.ptr, 0, 96 * sizeof(int), d.stream()));
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.counts.ptr, 0, ((size_t)nb1 * e.nblk1 + 1) * sizeof(int), d.stream()));
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.counts2.ptr, 0, ((size_t)nb2 * e.nblk_g + 1) * sizeof(int), d.stream()));
+            // (one launch: the error word, both count arrays, and the guard words of the step that follows the rebuild)
+            Zeros().add(d.small.ptr + 95, 1).add(d.counts.ptr, (size_t)nb1 * e.nblk1 + 1).add(d.counts2.ptr, (size_t)nb2 * e.nblk_g + 1)
+                .add(d.words.ptr, DD_WORDS).run(d.stream());
+            d.words_clear = true;
             // ---- 1. owner of every atom, where the engine keeps it; the ghost directions of those that stay
             hipLaunchKernelGGL((k_dd_classify_sorted<real>), dim3(e.nblk1), dim3(PART_BLOCK), 0, d.stream(), e.n, sy.n_owned, sy.perm.ptr,
                                sy.rec.ptr, d.geo.template device<real>(), d.keep.ptr, d.mask.ptr, d.gmask.ptr, d.small.ptr + 95, nb1,
                                e.nblk1, d.counts.ptr, nb2, e.nblk_g, d.counts2.ptr);
-            DdBins pb{};
-            pb.npeers = np;
-            for (int p = 0; p <= np + 1; p++) pb.lo[p] = std::min(1 + p, 1 + np);
-            partition_finish(d, nb1, e.nblk1, pb);
-            hipLaunchKernelGGL(k_part_scatter, dim3(e.nblk1), dim3(PART_BLOCK), 0, d.stream(), e.q_arr, d.mask.ptr, nb1, e.nblk1,
-                               d.counts.ptr, d.ids.ptr, (int *)nullptr, (const int *)nullptr, e.mig + PART_BLOCK);
+            d.scanner.run(d.counts.ptr, (size_t)nb1 * e.nblk1 + 1, d.stream());
+            if (np > 0)
+                hipLaunchKernelGGL(k_part_scatter, dim3(e.nblk1), dim3(PART_BLOCK), 0, d.stream(), e.q_arr, d.mask.ptr, nb1, e.nblk1,
+                                   d.counts.ptr, d.ids.ptr, (int *)nullptr, (const int *)nullptr, e.mig + PART_BLOCK);
             // ---- 2. the leavers travel in padded messages
             const int nt = std::max(1, std::max(np, e.mig));
-            hipLaunchKernelGGL((k_dd_pack_migrants_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
-                               d.small.ptr, d.ids.ptr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr, d.sendbuf.ptr);
+            if (np > 0)
+                hipLaunchKernelGGL((k_dd_pack_migrants_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
+                                   PartView{d.counts.ptr, e.nblk1}, d.ids.ptr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr, d.sendbuf.ptr);
             for (int p = 0; p < np; p++) {
                 d.xf.soff[p] = d.xf.roff[p] = dd_pad_msg_begin(d.mig_caps, p, mrow);
                 d.xf.sbytes[p] = d.xf.rbytes[p] = dd_pad_msg_bytes(d.mig_caps, p, mrow);
@@ -907,20 +908,19 @@ struct DdImpl : IDd {
             NbSystem<real> &sy = d.sys();
             const int np = d.geo.npeers, nb2 = std::max(1, d.geo.ghost_nbins);
             // ---- 3. arrivals behind the old state; ghosts: which neighbours need which of my (new) atoms
-            hipLaunchKernelGGL((k_dd_unpack_arrivals<real>), dim3(e.nblk_arr), dim3(PART_BLOCK), 0, d.stream(), d.mig_caps, d.small.ptr,
-                               d.small.ptr + 95, d.recvbuf.ptr, d.n_owned, e.q_arr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr,
+            hipLaunchKernelGGL((k_dd_unpack_arrivals<real>), dim3(e.nblk_arr), dim3(PART_BLOCK), 0, d.stream(), d.mig_caps,
+                               PartView{d.counts.ptr, e.nblk1}, d.small.ptr + 95, d.recvbuf.ptr, d.n_owned, e.q_arr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr,
                                d.keep.ptr, d.gmask.ptr, d.geo.template device<real>(), nb2, e.nblk_g, d.counts2.ptr, e.nblk1, d.w.ptr);
             DdBins pb{};
             pb.npeers = np;
             for (int p = 0; p <= np + 1; p++) pb.lo[p] = d.geo.peer_bin_lo[std::min(p, np)];
             d.scanner.run(d.counts2.ptr, (size_t)nb2 * e.nblk_g + 1, d.stream());
-            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, d.stream(), nb2, e.nblk_g, d.counts2.ptr, d.small2.ptr, pb, d.small2.ptr + 33);
             if (d.geo.ghost_nbins > 0)
                 hipLaunchKernelGGL(k_part_scatter, dim3(e.nblk_g), dim3(PART_BLOCK), 0, d.stream(), e.ghost_base, d.gmask.ptr, nb2, e.nblk_g,
                                    d.counts2.ptr, d.ids.ptr, d.bins.ptr, (const int *)nullptr, d.gs_caps.start[np]);
             const int nt = std::max(1, std::max(np, d.gs_caps.start[np]));
             hipLaunchKernelGGL((k_dd_pack_ghost_rows_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.gs_caps,
-                               d.small2.ptr + 33, d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), sy.rec.ptr, sy.te.ptr, sy.tag.ptr,
+                               PartView{d.counts2.ptr, e.nblk_g}, pb, d.ids.ptr, d.bins.ptr, d.geo.template device<real>(), sy.rec.ptr, sy.te.ptr, sy.tag.ptr,
                                d.sendbuf.ptr, d.codes.ptr, d.w.ptr);
             for (int p = 0; p < np; p++) {
                 d.xf.soff[p] = dd_pad_msg_begin(d.gs_caps, p, grow); d.xf.sbytes[p] = dd_pad_msg_bytes(d.gs_caps, p, grow);
@@ -939,8 +939,11 @@ struct DdImpl : IDd {
             const Slots &e = S[l];
             NbSystem<real> &sy = d.sys();
             const int np = d.geo.npeers;
+            DdBins pb4{};
+            pb4.npeers = np;
+            for (int p = 0; p <= np + 1; p++) pb4.lo[p] = d.geo.peer_bin_lo[std::min(p, np)];
             hipLaunchKernelGGL((k_dd_unpack_ghost_rows_sorted<real>), dim3(blocks_for(std::max(1, e.gr), 256)), dim3(256), 0, d.stream(),
-                               d.gs_caps, d.gr_caps, d.small2.ptr + 33, d.recvbuf.ptr, e.ghost_base, sy.rec.ptr, sy.te.ptr, sy.vel.ptr,
+                               d.gs_caps, d.gr_caps, PartView{d.counts2.ptr, e.nblk_g}, pb4, d.recvbuf.ptr, e.ghost_base, sy.rec.ptr, sy.te.ptr, sy.vel.ptr,
                                sy.pitch, sy.tag.ptr, d.keep.ptr, d.w.ptr);
             typename NbSystem<real>::EditWords extra;
             extra.dev = d.w.ptr; extra.n = DDW_COUNT; extra.host = d.host_w;
@@ -958,7 +961,7 @@ struct DdImpl : IDd {
             EMDEE_REQUIRE((pd->host_w[DDW_OVER] != 0) == over, EMDEE_ERR_STATE,
                           "emdee_dd: the domains disagree on whether a rebuild message overflowed (domain %d)", pd->geo.rank);
         if (over) {
-            for (auto &pd : dom) pd->sys().rollback_edit();
+            for (auto &pd : dom) { pd->sys().rollback_edit(); pd->words_clear = false; }
             return false;
         }
         for (size_t l = 0; l < dom.size(); l++) {
@@ -1181,7 +1184,9 @@ struct DdImpl : IDd {
     void step_after_rebuild(double dt) {
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
-            EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            // (a rebuild in the engine's order has cleared the words with its first launch: nothing between its read-back and the step)
+            if (!d.words_clear) EMDEE_HIP_CHECK(hipMemsetAsync(d.words.ptr, 0, DD_WORDS * sizeof(int), d.stream()));
+            d.words_clear = false;
             if (d.sys().n_total > 0) {
                 const bool tiled = d.sys().brick_active && !(d.md->current_mask & EMDEE_FORCES) &&
                                    d.sys().fused_step(dt, dt, 0, nullptr, d.V(0), false, false);

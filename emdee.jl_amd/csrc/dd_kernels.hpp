@@ -63,7 +63,18 @@ static inline size_t dd_msg_bytes(const int *start, int p, size_t w) { return DD
 // seven neighbours).  Output: for every bin, the ids of its items in ascending order -- deterministic, no
 // atomics on the output.  count -> exclusive scan of counts[bin][block] -> scatter.  The kernels that produce the
 // masks (ownership, ghost selection) count their block themselves: blocks of PART_BLOCK items.
-constexpr int PART_BLOCK = 256;
+constexpr int PART_BLOCK = 1024;     // (1024: the count arrays of a rank-sized domain -- bins x blocks -- fit one launch of k_scan_block)
+
+struct DdBins {                      // the bins of a partition that belong to peer p: lo[p] .. lo[p+1]-1
+    int npeers;
+    int lo[DD_MAX_PEERS + 2];
+};
+// the scanned counts of a partition, as its consumers read them: first output position of bin b = offs[b * nblocks]
+struct PartView {
+    const int *offs;
+    int nblocks;
+    __device__ __forceinline__ int start(int bin) const { return offs[(size_t)bin * nblocks]; }
+};
 
 // every thread of the block calls this with the mask of its item (0 past the end)
 __device__ __forceinline__ void part_count_block(unsigned m, int nbins, int nblocks, int *__restrict__ counts) {
@@ -169,10 +180,6 @@ static __global__ __launch_bounds__(PART_BLOCK) void k_part_scatter(int n, const
 }
 
 // bin_start[0..nbins] from the scanned counts; peer_count[p] = entries bound for peer p (bins lo[p] .. lo[p+1]-1)
-struct DdBins {
-    int npeers;
-    int lo[DD_MAX_PEERS + 2];
-};
 static __global__ void k_part_starts(int nbins, int nblocks, const int *__restrict__ offs, int *__restrict__ bin_start,
                                      DdBins pb, int *__restrict__ peer_count) {
     const int t = threadIdx.x;
@@ -376,22 +383,22 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_classify_sorted(int n, int ow
 
 // leavers -> padded messages (ids[bin_start[1 + p] + slot], the stable partition's order), out of the engine's arrays; headers
 template <typename real>
-__global__ void k_dd_pack_migrants_sorted(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ ids,
+__global__ void k_dd_pack_migrants_sorted(DdCaps caps, PartView lv, const int *__restrict__ ids,
                                           const Rec<real> *__restrict__ rec, const float *__restrict__ te,
                                           const real *__restrict__ vel, size_t pitch, const long long *__restrict__ tag,
                                           unsigned char *__restrict__ buf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < caps.npeers) {
         int over = 0;
-        for (int q = 0; q < caps.npeers; q++) over |= (bin_start[2 + q] - bin_start[1 + q]) > (caps.start[q + 1] - caps.start[q]);
+        for (int q = 0; q < caps.npeers; q++) over |= (lv.start(2 + q) - lv.start(1 + q)) > (caps.start[q + 1] - caps.start[q]);
         int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(MigRow<real>)) - DD_RHDR);
-        hdr[0] = bin_start[2 + t] - bin_start[1 + t]; hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
+        hdr[0] = lv.start(2 + t) - lv.start(1 + t); hdr[1] = over; hdr[2] = 0; hdr[3] = 0;
     }
     if (t >= caps.start[caps.npeers]) return;
     const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
-    if (slot >= bin_start[2 + p] - bin_start[1 + p]) return;
+    if (slot >= lv.start(2 + p) - lv.start(1 + p)) return;
     if (!EMDEE_BOUND(BS_DD_MIG_PACK, slot, caps.start[p + 1] - caps.start[p])) return;
-    const int i = ids[bin_start[1 + p] + slot];
+    const int i = ids[lv.start(1 + p) + slot];
     const Rec<real> a = rec[i];
     MigRow<real> r;
     r.x[0] = a.x; r.x[1] = a.y; r.x[2] = a.z;
@@ -406,7 +413,7 @@ __global__ void k_dd_pack_migrants_sorted(DdCaps caps, const int *__restrict__ b
 // receive buffer -> slot q_arr + t behind the old state (record, velocities, global id, ghost directions), unused rows struck
 // out; thread 0: the counts of the migration and the overflow word (mine or anybody's) for the read-back.
 template <typename real>
-__global__ __launch_bounds__(PART_BLOCK) void k_dd_unpack_arrivals(DdCaps caps, const int *__restrict__ bin_start, const int *__restrict__ err,
+__global__ __launch_bounds__(PART_BLOCK) void k_dd_unpack_arrivals(DdCaps caps, PartView lv, const int *__restrict__ err,
                                                                    const unsigned char *__restrict__ recv, int n_owned_old, int q_arr,
                                                                    Rec<real> *__restrict__ rec, float *__restrict__ te,
                                                                    real *__restrict__ vel, size_t pitch, long long *__restrict__ tag,
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_unpack_arrivals(DdCaps caps, 
         for (int p = 0; p < caps.npeers; p++) {
             const int cap = caps.start[p + 1] - caps.start[p];
             const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(caps, p, sizeof(MigRow<real>)) - DD_RHDR);
-            const int out = bin_start[2 + p] - bin_start[1 + p];
+            const int out = lv.start(2 + p) - lv.start(1 + p);
             over |= hdr[1] | (hdr[0] > cap) | (out > cap);
             const int in = min(max(hdr[0], 0), cap);
             w[DDW_ARRIVE + p] = in;
@@ -457,28 +464,29 @@ __global__ __launch_bounds__(PART_BLOCK) void k_dd_unpack_arrivals(DdCaps caps, 
 // ghost rows -> padded messages, out of the engine's arrays; peer_count[p] = entries bound for peer p (k_part_starts), list
 // entry k of peer p sits at sum of the counts before p + slot; codes[k] = direction, for the per-step messages
 template <typename real>
-__global__ void k_dd_pack_ghost_rows_sorted(DdCaps caps, const int *__restrict__ peer_count, const int *__restrict__ ids,
+__global__ void k_dd_pack_ghost_rows_sorted(DdCaps caps, PartView gv, DdBins pb, const int *__restrict__ ids,
                                             const int *__restrict__ bins, DdDev<real> g, const Rec<real> *__restrict__ rec,
                                             const float *__restrict__ te, const long long *__restrict__ tag,
                                             unsigned char *__restrict__ buf, int *__restrict__ codes, const int *__restrict__ w_over) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    auto peer_count = [&](int q) { return gv.start(pb.lo[q + 1]) - gv.start(pb.lo[q]); };   // entries bound for peer q
     int over = w_over[DDW_OVER];
-    for (int q = 0; q < caps.npeers; q++) over |= peer_count[q] > (caps.start[q + 1] - caps.start[q]);
+    for (int q = 0; q < caps.npeers; q++) over |= peer_count(q) > (caps.start[q + 1] - caps.start[q]);
     if (t < caps.npeers) {
         int *hdr = reinterpret_cast<int *>(buf + dd_pad_begin(caps, t, sizeof(GhostRow<real>)) - DD_RHDR);
         // hdr[2]: my error word (an atom that left the neighbourhood of its brick) -- every rank neighbours every other one, so
         // all of them see it in this exchange and fail together, instead of one throwing while the others walk into the next
         // step's send / receive with a peer that is gone
-        hdr[0] = peer_count[t]; hdr[1] = over; hdr[2] = w_over[DDW_ERR]; hdr[3] = 0;
+        hdr[0] = peer_count(t); hdr[1] = over; hdr[2] = w_over[DDW_ERR]; hdr[3] = 0;
     }
     // an overflow anywhere: the rebuild will be redone with counts and no row of this one is looked at -- and the send
     // list (ids, bins, codes: sized by the capacities) does not hold what the counts say
     // (bounds build, test of the checker itself: debug_inject puts the pre-2d85cf1 behaviour back -- the list indexed by the counts)
     if ((over && !caps.debug_inject) || t >= caps.start[caps.npeers]) return;
     const int p = dd_caps_peer(caps, t), slot = t - caps.start[p];
-    if (slot >= peer_count[p]) return;
+    if (slot >= peer_count(p)) return;
     int k = slot;
-    for (int q = 0; q < p; q++) k += peer_count[q];
+    for (int q = 0; q < p; q++) k += peer_count(q);
     if (!EMDEE_BOUND(BS_DD_GHOST_PACK, k, caps.start[caps.npeers])) return;   // the send list (ids, bins, codes) holds start[npeers] entries
     const int i = ids[k], dir = g.bin_dir[bins[k]];
     const Rec<real> a = rec[i];
@@ -494,7 +502,7 @@ __global__ void k_dd_pack_ghost_rows_sorted(DdCaps caps, const int *__restrict__
 // ghost_base + t (record, global id), unused rows struck out; thread 0: send / receive counts per peer, totals, the overflow
 // and error words of either exchange (mine or a peer's: the same words on every rank).
 template <typename real>
-__global__ void k_dd_unpack_ghost_rows_sorted(DdCaps scaps, DdCaps rcaps, const int *__restrict__ peer_count,
+__global__ void k_dd_unpack_ghost_rows_sorted(DdCaps scaps, DdCaps rcaps, PartView gv, DdBins pb,
                                               const unsigned char *__restrict__ recv, int ghost_base, Rec<real> *__restrict__ rec,
                                               float *__restrict__ te, real *__restrict__ vel, size_t pitch,
                                               long long *__restrict__ tag, unsigned char *__restrict__ keep, int *__restrict__ w) {
@@ -504,11 +512,12 @@ __global__ void k_dd_unpack_ghost_rows_sorted(DdCaps scaps, DdCaps rcaps, const 
         for (int p = 0; p < scaps.npeers; p++) {
             const int rcap = rcaps.start[p + 1] - rcaps.start[p], scap = scaps.start[p + 1] - scaps.start[p];
             const int *hdr = reinterpret_cast<const int *>(recv + dd_pad_begin(rcaps, p, sizeof(GhostRow<real>)) - DD_RHDR);
-            over |= hdr[1] | (hdr[0] > rcap) | (peer_count[p] > scap);
+            const int mine = gv.start(pb.lo[p + 1]) - gv.start(pb.lo[p]);      // entries bound for peer p
+            over |= hdr[1] | (hdr[0] > rcap) | (mine > scap);
             err |= hdr[2];
-            w[DDW_GSEND + p] = peer_count[p];
+            w[DDW_GSEND + p] = mine;
             w[DDW_GRECV + p] = hdr[0];
-            nsend += peer_count[p];
+            nsend += mine;
             nghost += hdr[0];
         }
         w[DDW_OVER] = over;

@@ -215,12 +215,6 @@ static __global__ void k_species_collect(int n, const emdee_lj_atom *__restrict_
     }
     if (__ballot(pending) != 0 && lane == 0) tab[MAX_SPECIES] = 1;   // a wavefront with more distinct keys than the table holds
 }
-// cstart[c] = first slot of cell c, from the per-(cell, species) starts of a typed sort
-static __global__ void k_cell_starts(int ncell, int nt, const int *__restrict__ tstart, int *__restrict__ cstart) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= ncell) cstart[c] = tstart[(size_t)c * nt];
-}
-
 // ------------------------------------------------------------------------------------ binning
 // Runs of equal keys among the 64 lanes of a wavefront (adjacent lanes only).  When the input is already
 // nearly cell-ordered -- every MD rebuild -- a wavefront spans ~4 cells, so one atomic per RUN instead of one
@@ -373,6 +367,73 @@ static __global__ void k_scan_add(int *__restrict__ out, size_t n, const int *__
     if (i < n) out[i] += offs[i / SCAN_TILE];
 }
 
+// One workgroup scans up to a few ten thousand values in place (4096 per trip: coalesced 16-byte loads, a block scan, a
+// carry): the count arrays of the decomposition's partitions, for which three launches of the tiled scan were three launch
+// latencies behind a blocking read-back.
+constexpr int SCAN_BLOCK_MAX = 65536;
+static __global__ __launch_bounds__(1024) void k_scan_block(int *__restrict__ data, int n) {
+    __shared__ int wtot[1024 / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + (int)threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? data[i0 + k] : 0;
+        const int s = v[0] + v[1] + v[2] + v[3];
+        int inc = s;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == WAVE - 1) wtot[wv] = inc;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / WAVE; w++) {
+            if (w < wv) woff += wtot[w];
+            tot += wtot[w];
+        }
+        int run = carry + woff + inc - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) data[i0 + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+// Several small zero-fills in ONE launch (a hipMemsetAsync whose size is not a multiple of 16 bytes is two fill kernels,
+// and every launch behind a blocking read-back is a launch latency on the critical path of a rebuild)
+struct ZeroRanges {
+    int *ptr[6];
+    unsigned n[6];
+};
+static __global__ void k_zero_ranges(ZeroRanges z) {
+    int *p = z.ptr[blockIdx.y];
+    const unsigned n = z.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+struct Zeros {
+    ZeroRanges z{};
+    int count = 0;
+    unsigned most = 0;
+    Zeros &add(int *p, size_t n) {
+        if (n == 0) return *this;
+        z.ptr[count] = p; z.n[count] = (unsigned)n; count++;
+        most = n > most ? (unsigned)n : most;
+        return *this;
+    }
+    void run(hipStream_t s) {
+        if (count == 0) return;
+        const unsigned bx = most <= 256 ? 1u : (most + 1023u) / 1024u;
+        hipLaunchKernelGGL(k_zero_ranges, dim3(bx > 512u ? 512u : bx, count), dim3(256), 0, s, z);
+    }
+};
+
 // ------------------------------------------------------------------------------------ gathers
 template <typename real>
 __device__ __forceinline__ void store_rec(Rec<real> *rec, float *te, int p, real x, real y, real z, float hs, float tev);
@@ -426,8 +487,12 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
                               real *__restrict__ xb, real *__restrict__ v_out, real *__restrict__ im_out,
                               int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
                               int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
-                              long long *__restrict__ tag_out = nullptr) {
+                              long long *__restrict__ tag_out = nullptr, int ncell = 0, int *__restrict__ cstart = nullptr,
+                              const int *__restrict__ tstart = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // (typed boxes and x sub-bins: the first slot of every CELL from the per-(cell, digit) starts -- rides here instead of
+    // being a launch of its own)
+    if (cstart) for (int c = p; c <= ncell; c += gridDim.x * blockDim.x) cstart[c] = tstart[(size_t)c * nt];
     if (p >= n) return;
     int i = order[p];
     if (tag_out) tag_out[p] = tag_in[i];
@@ -464,8 +529,10 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
                                 int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
                                 int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
                                 long long *__restrict__ tag_out = nullptr, const int *__restrict__ n_dev = nullptr,
-                                int *__restrict__ n_out = nullptr) {
+                                int *__restrict__ n_out = nullptr, int ncell = 0, int *__restrict__ cstart = nullptr,
+                                const int *__restrict__ tstart = nullptr) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cstart) for (int c = p; c <= ncell; c += gridDim.x * blockDim.x) cstart[c] = tstart[(size_t)c * nt];
     if (EDIT) {
         n = min(n, *n_dev);
         if (p == 0 && n_out) *n_out = *n_dev;

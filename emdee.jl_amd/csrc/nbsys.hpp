@@ -25,6 +25,10 @@ struct Scanner {
     DevBuf<int> scratch;
     void run(int *data, size_t n, hipStream_t s) {
         if (n == 0) return;
+        if (n <= (size_t)SCAN_BLOCK_MAX) {
+            hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(1024), 0, s, data, (int)n);
+            return;
+        }
         size_t total = 0;
         for (size_t m = n; m > 1;) {
             m = (m + SCAN_TILE - 1) / SCAN_TILE;
@@ -286,12 +290,13 @@ struct NbSystem {
         const int dm = digits();
         const size_t nbins = ncell * (size_t)dm;
         count.ensure(nbins + 2); fill.ensure(nbins + 2);
-        EMDEE_HIP_CHECK(hipMemsetAsync(count.ptr, 0, (nbins + 1) * sizeof(int), stream()));
-        EMDEE_HIP_CHECK(hipMemsetAsync(fill.ptr, 0, nbins * sizeof(int), stream()));
+        Zeros zr;
+        zr.add(count.ptr, nbins + 1).add(fill.ptr, nbins);
         if (dm > 1) {
             cstart.ensure(ncell + 2);
-            if (n == 0) EMDEE_HIP_CHECK(hipMemsetAsync(cstart.ptr, 0, (ncell + 1) * sizeof(int), stream()));
+            if (n == 0) zr.add(cstart.ptr, ncell + 1);
         }
+        zr.run(stream());
         if (n == 0) return;
         hipLaunchKernelGGL((k_cell_assign<real, Src, Spc>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, src, grid,
                            cell_of.ptr, count.ptr, spc, dm, keep);
@@ -301,8 +306,7 @@ struct NbSystem {
                            fill.ptr, key, tmp2.ptr, tagkey);
         hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            tmp2.ptr, order.ptr, keep ? count.ptr + nbins : nullptr);
-        if (dm > 1)
-            hipLaunchKernelGGL(k_cell_starts, dim3(blocks_for(ncell + 1, 256)), dim3(256), 0, stream(), (int)ncell, dm, count.ptr, cstart.ptr);
+        // (the first slot of every cell, cstart[], is written by the gather kernel that follows)
     }
     // K: how many quarters of a neighbour cell lie beyond r_list whatever the atom's position in its own quarter: the
     // quarters < s + K of the left cell are at least (1 + (K - 1) / 4) cell widths away.  0 for a cell a little wider than
@@ -348,7 +352,8 @@ struct NbSystem {
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img.ptr, digits(), use_tags ? tags_user : nullptr, use_tags ? tag.ptr : nullptr);
+                               cell_sorted.ptr, img.ptr, digits(), use_tags ? tags_user : nullptr, use_tags ? tag.ptr : nullptr,
+                               (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
         // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
         // from the start; their coordinates are refreshed by every halo unpack
         if (has_ghosts)
@@ -373,7 +378,8 @@ struct NbSystem {
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
                                with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img2.ptr, digits(), tk, use_tags ? tag2.ptr : nullptr);
+                               cell_sorted.ptr, img2.ptr, digits(), tk, use_tags ? tag2.ptr : nullptr, (const int *)nullptr,
+                               (int *)nullptr, (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
         swap_sorted_buffers();
         build_list();
     }
@@ -417,7 +423,7 @@ struct NbSystem {
         hipLaunchKernelGGL((k_gather_sorted<real, true>), dim3(blocks_for(n_items, 256)), dim3(256), 0, stream(), n_items, pitch, grid,
                            order.ptr, cell_of.ptr, rec.ptr, te.ptr, vel.ptr, (const real *)nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr,
                            xb.ptr, vel2.ptr, (real *)nullptr, perm2.ptr, inv_perm.ptr, cell_sorted.ptr, img2.ptr, digits(), tag.ptr,
-                           tag2.ptr, count.ptr + nbins, n_live_dev);
+                           tag2.ptr, count.ptr + nbins, n_live_dev, (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
         swap_sorted_buffers();
         edit_n_plan = n_total;
         n_total = n_items;                                  // an upper bound until commit_edit()
@@ -614,10 +620,12 @@ struct NbSystem {
         });
     }
     // flags[6] = largest tile, flags[7] = most own atoms of a brick, flags[8] = most atoms in three consecutive cells of a tile row
-    void launch_tile_max() {
+    // (with_build_words: the build's own words flags[0..5) are cleared by the same launch -- the first attempt of build_list)
+    void launch_tile_max(bool with_build_words = false) {
         with_brick_variant(variant, [&](auto v) {
             using S = typename decltype(v)::Shape;
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 6, 0, 3 * sizeof(int), stream()));
+            if (with_build_words) Zeros().add(flags.ptr, 9).run(stream());
+            else Zeros().add(flags.ptr + 6, 3).run(stream());
             hipLaunchKernelGGL((k_brick_tile_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
                                grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], start(),
                                flags.ptr + 6);
@@ -828,8 +836,8 @@ struct NbSystem {
             // lost: one workgroup per brick means one look at -- or atomic on -- three hot words per brick, 2.84 -> 2.95 ms per
             // rebuild even with a device-scope look before the atomic, 4.50 ms without; k_brick_tile_max reduces 64 bricks per
             // wavefront first.  EMDEE_PLAN_MAXIMA=tables switches it on)
-            if (maxima_from_tables) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 6, 0, 3 * sizeof(int), stream()));
-            else launch_tile_max();
+            if (maxima_from_tables) Zeros().add(flags.ptr, 9).run(stream());
+            else launch_tile_max(true);
             brick_active = true;
         } else {
             make_plan();
@@ -839,7 +847,7 @@ struct NbSystem {
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             if (in_edit && !brick_active) { edit_abort = true; return; }   // (the direct kernels count atoms on the host: the caller reloads)
-            EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 5 * sizeof(int), stream()));
+            if (!(kept && attempt == 0)) Zeros().add(flags.ptr, 5).run(stream());   // (a kept plan cleared them with the maxima)
             if (brick_active) {
                 nbr16.ensure(rows * stride);
                 with_brick_variant(variant, [&](auto v) {
