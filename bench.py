@@ -566,7 +566,11 @@ def main():
                          "halo_ms": per("halo"), "rebuild_device_ms": per("rebuild"),
                          "rebuild_wall_ms": (phase1["rebuild_ms"] - phase0["rebuild_ms"]) / args.steps,
                          "readback_wall_ms": (phase1["readback_ms"] - phase0["readback_ms"]) / args.steps,
-                         "readbacks": phase1["readbacks"] - phase0["readbacks"], "rebuilds": phase1["rebuilds"] - phase0["rebuilds"]})
+                         "readbacks": phase1["readbacks"] - phase0["readbacks"], "rebuilds": phase1["rebuilds"] - phase0["rebuilds"],
+                         # a rebuild = the read-back of the batch's request words that asked for it + those inside it (ONE, with
+                         # the build's words, when it ran in the engines' own order)
+                         "rebuilds_in_engine_order": phase1["rebuilds_in_engine_order"] - phase0["rebuilds_in_engine_order"],
+                         "readbacks_per_rebuild": 1.0 + (phase1["rebuild_readbacks"] - phase0["rebuild_readbacks"]) / max(phase1["rebuilds"] - phase0["rebuilds"], 1)})
         ranks = mine
         if dist is not None:
             gathered = [None] * world

@@ -193,6 +193,9 @@ struct FenceOut {
     bool live;
     FenceOut(const emdee_ctx *caller_ctx, hipStream_t engine_stream)
         : caller(caller_ctx ? caller_ctx->stream : nullptr), engine(engine_stream), live(caller_ctx != nullptr && caller_ctx->stream != engine_stream) {
+#ifdef EMDEE_NO_FENCE                                     // (A/B build only, profiles/build_variant.sh: shows that the test of the fence sees the race)
+        live = false;
+#endif
         if (live) hop(caller, engine);
     }
     ~FenceOut() {

@@ -99,6 +99,7 @@ struct DdGeom {
     int dir_of_bin[DD_MAX_DIRS];         // send-list bins: directions sorted by (destination rank, direction)
     int bin_of_dir[DD_MAX_DIRS];
     int peer_bin_lo[DD_MAX_PEERS + 2];   // bins of peer p: [peer_bin_lo[p], peer_bin_lo[p+1])
+    bool mirror = false;                 // DdImpl::mirror: every peer is this domain's own periodic image
 
     int peer_index(int r) const {
         for (int p = 0; p < npeers; p++)
@@ -178,6 +179,22 @@ struct DdGeom {
         for (int r = 0; r < DD_MAX_WORLD; r++) g.rank_bin[r] = -1;
         g.rank_bin[rank] = 0;
         for (int p = 0; p < npeers; p++) g.rank_bin[peers[p]] = 1 + p;
+        for (int b = 0; b <= DD_MAX_PEERS; b++)
+            for (int d = 0; d < 3; d++) g.mig_off[b][d] = (real)0;
+        if (mirror) {
+            // The replica rehearsal: what a peer sends me is what I send it, seen from my side.  An atom of mine in the halo of
+            // my face in direction s is the peer's atom in the halo of ITS face in direction s (grids of <= 2 bricks per
+            // dimension: s reaches the same peer both ways), which the peer sends me as a ghost on my OTHER side -- my atom
+            // moved by -s times the brick width; an atom that leaves me for the brick at coordinates c arrives from there in my
+            // own brick, moved by -(c - mine) widths.
+            for (int k = 0; k < ndirs; k++)
+                for (int d = 0; d < 3; d++) g.shift[k][d] = (real)(-dir[k][d] * width[d]);
+            for (int p = 0; p < npeers; p++) {
+                const int r = peers[p];
+                const int c[3] = {r % grid[0], (r / grid[0]) % grid[1], r / (grid[0] * grid[1])};
+                for (int d = 0; d < 3; d++) g.mig_off[1 + p][d] = (real)((c[d] - coords[d]) * width[d]);
+            }
+        }
         return g;
     }
 };
@@ -243,6 +260,14 @@ struct DdImpl : IDd {
     std::vector<std::unique_ptr<Domain<real>>> dom;   // local domains, ranks rank_first .. rank_first + n_local - 1
     int rank_first, n_local;
     bool use_rccl = false;
+    // The replica rehearsal of ONE rank on one device (n_local = 1 of a larger grid, no communicator id): every peer is taken
+    // to hold this domain's own atoms, moved by whole brick widths -- the box is then periodic with the BRICK's period, and
+    // what a peer would send is what this domain sends it, seen from this side (DdGeom::device).  Transport: a copy of the
+    // send buffer's messages into the receive buffer.  Everything else -- seven peers, 26 directions, migration, ghost
+    // selection, padded messages, the per-step halo on its own stream, batches and guard words -- is the production path
+    // with the production message sizes: the cost of one rank of an N-rank run, minus the links, measured on one GPU; and
+    // the run must reproduce the undivided periodic box of one brick (tests/test_gpu_dd.py).
+    bool mirror = false;
     RcclApi::Comm comm = nullptr;
     bool loaded = false;
     int64_t n_global = 0;
@@ -290,11 +315,12 @@ struct DdImpl : IDd {
                       "emdee_dd: local ranks [%d, %d) outside the %d-domain grid", rank_first, rank_first + n_local, world);
         EMDEE_REQUIRE(m.rc2 > 0 && skin >= 0, EMDEE_ERR_INVALID, "emdee_dd: bad model or skin");
         halo = std::sqrt(m.rc2) + skin;
-        use_rccl = n_local < world;
-        if (use_rccl) {
-            EMDEE_REQUIRE(n_local == 1, EMDEE_ERR_INVALID, "emdee_dd: one domain per process when the domains span processes");
-            EMDEE_REQUIRE(unique_id != nullptr, EMDEE_ERR_INVALID, "emdee_dd: a communicator id (emdee_dd_unique_id) is needed");
-        }
+        use_rccl = n_local < world && unique_id != nullptr;
+        mirror = n_local < world && unique_id == nullptr;
+        if (n_local < world) EMDEE_REQUIRE(n_local == 1, EMDEE_ERR_INVALID, "emdee_dd: one domain per process when the domains span processes");
+        if (mirror)
+            for (int d = 0; d < 3; d++)
+                EMDEE_REQUIRE(g[d] <= 2, EMDEE_ERR_INVALID, "emdee_dd: the replica rehearsal (one local domain, no communicator id) needs at most 2 bricks per dimension");
         if (const char *e = std::getenv("EMDEE_DD_BATCH")) max_batch = std::max(1, std::min(DD_MAX_BATCH, std::atoi(e)));
         if (const char *e = std::getenv("EMDEE_DD_OVERLAP")) overlap = std::atoi(e) != 0;
         if (const char *e = std::getenv("EMDEE_DD_STREAMS")) two_streams = std::atoi(e) != 1;
@@ -307,7 +333,8 @@ struct DdImpl : IDd {
             dom.push_back(std::make_unique<Domain<real>>());   // registered first: release() sees whatever it gets below
             Domain<real> *d = dom.back().get();
             d->geo.init(L, grid, halo, rank_first + l);
-            if (use_rccl) {
+            d->geo.mirror = mirror;
+            if (use_rccl || mirror) {
                 d->ctx = c;
             } else {
                 d->ctx = new emdee_ctx(*c);
@@ -382,7 +409,7 @@ struct DdImpl : IDd {
     // The exchanges of a rebuild (counts, migrants, ghost rows) have nothing to overlap with and always go in order.
     bool in_rebuild = false;
     bool force_inline = false;            // (lock-step halves: the exchange is queued on whatever stream the domain points at)
-    bool inline_exchange() const { return (!overlap || in_rebuild || force_inline) && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0); }
+    bool inline_exchange() const { return (!overlap || in_rebuild || force_inline) && dom.size() == 1 && (use_rccl || mirror || dom[0]->geo.npeers == 0); }
     void record_packed(Domain<real> &d) {
         if (!inline_exchange()) EMDEE_HIP_CHECK(hipEventRecord(d.ev_packed, d.stream()));
     }
@@ -402,6 +429,26 @@ struct DdImpl : IDd {
                 EMDEE_RCCL_CHECK(api.GroupEnd());
             }
             if (!inl) EMDEE_HIP_CHECK(hipEventRecord(d.ev_done, d.comm));
+            return;
+        }
+        if (mirror) {
+            // every peer is my own image: its message is mine (the pack kernels wrote it as the peer would have)
+            Domain<real> &d = *dom[0];
+            hipStream_t cs = inl ? d.stream() : d.comm;
+            if (!inl) EMDEE_HIP_CHECK(hipStreamWaitEvent(d.comm, d.ev_packed, 0));
+            PullArgs pa{};
+            unsigned most = 0;
+            for (int p = 0; p < d.geo.npeers; p++) {
+                EMDEE_REQUIRE(d.xf.sbytes[p] == d.xf.rbytes[p], EMDEE_ERR_STATE, "emdee_dd: replica messages of different sizes (%zu sent, %zu expected)", d.xf.sbytes[p], d.xf.rbytes[p]);
+                if (d.xf.rbytes[p] == 0) continue;
+                PullSeg &g = pa.seg[pa.n++];
+                g.src = reinterpret_cast<const unsigned *>(d.xf.send + d.xf.soff[p]);
+                g.dst = reinterpret_cast<unsigned *>(d.xf.recv + d.xf.roff[p]);
+                g.words = (unsigned)(d.xf.rbytes[p] / 4);
+                most = std::max(most, g.words);
+            }
+            if (pa.n > 0) hipLaunchKernelGGL(k_dd_pull, dim3(std::min(64u, blocks_for(most, 1024)), pa.n), dim3(256), 0, cs, pa);
+            if (!inl) EMDEE_HIP_CHECK(hipEventRecord(d.ev_done, cs));
             return;
         }
         if (inl) return;                                       // one domain without peers: nobody to copy from
@@ -446,6 +493,8 @@ struct DdImpl : IDd {
         for (int k = 0; k < n; k++) out[k] = 0.0;
         for (auto &v : vals)
             for (int k = 0; k < n; k++) out[k] += v[k];
+        if (mirror)
+            for (int k = 0; k < n; k++) out[k] *= (double)world;   // (every rank of the rehearsed grid holds the same)
         if (!use_rccl) return;
         Domain<real> &d = *dom[0];
         EMDEE_REQUIRE(n <= 8, EMDEE_ERR_INVALID, "allreduce_sum: at most 8 values");
@@ -640,6 +689,22 @@ struct DdImpl : IDd {
             std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
             ~Wall() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); n++; }
         } wall{stat_rebuild_wall_ms, stat_rebuild_calls};
+        struct Reads {                                             // blocking read-backs inside rebuilds (all local domains' contexts)
+            DdImpl *dd;
+            int64_t at;
+            static int64_t now(DdImpl *d) {
+                int64_t n = 0;
+                std::vector<const emdee_ctx *> seen;
+                for (auto &pd : d->dom) {
+                    if (std::find(seen.begin(), seen.end(), pd->ctx) != seen.end()) continue;
+                    seen.push_back(pd->ctx);
+                    n += pd->ctx->readbacks;
+                }
+                return n;
+            }
+            explicit Reads(DdImpl *d) : dd(d), at(now(d)) {}
+            ~Reads() { dd->stat_rebuild_readbacks += now(dd) - at; }
+        } reads(this);
         join_halo();
         for (auto &pd : dom) pd->words_clear = false;
         if (world == 1 && from_engines && !no_shortcut) {
@@ -699,9 +764,14 @@ struct DdImpl : IDd {
             for (int p = 0; p < d.geo.npeers; p++) n_arrive += d.host_small[60 + p];
             d.sendbuf.ensure((size_t)n_leave * sizeof(MigRow<real>) + 64);
             d.recvbuf.ensure((size_t)n_arrive * sizeof(MigRow<real>) + 64);
-            if (n_leave > 0)
+            if (n_leave > 0) {
+                DdBins st{};
+                st.npeers = d.geo.npeers;
+                for (int b = 0; b <= d.geo.npeers + 1 && b < DD_MAX_PEERS + 2; b++) st.lo[b] = d.host_small[std::min(b, nb)];
                 hipLaunchKernelGGL((k_dd_pack_migrants<real>), dim3(blocks_for(n_leave, 256)), dim3(256), 0, d.stream(), n_stay, total,
-                                   d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, reinterpret_cast<MigRow<real> *>(d.sendbuf.ptr));
+                                   d.ids.ptr, d.x.ptr, d.v.ptr, d.at.ptr, d.gid.ptr, reinterpret_cast<MigRow<real> *>(d.sendbuf.ptr),
+                                   d.geo.template device<real>(), st);
+            }
             stat_migrated += n_leave;
         }
         exchange_rows(sizeof(MigRow<real>));
@@ -891,7 +961,8 @@ struct DdImpl : IDd {
             const int nt = std::max(1, std::max(np, e.mig));
             if (np > 0)
                 hipLaunchKernelGGL((k_dd_pack_migrants_sorted<real>), dim3(blocks_for(nt, 256)), dim3(256), 0, d.stream(), d.mig_caps,
-                                   PartView{d.counts.ptr, e.nblk1}, d.ids.ptr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr, d.sendbuf.ptr);
+                                   PartView{d.counts.ptr, e.nblk1}, d.ids.ptr, sy.rec.ptr, sy.te.ptr, sy.vel.ptr, sy.pitch, sy.tag.ptr, d.sendbuf.ptr,
+                                   d.geo.template device<real>());
             for (int p = 0; p < np; p++) {
                 d.xf.soff[p] = d.xf.roff[p] = dd_pad_msg_begin(d.mig_caps, p, mrow);
                 d.xf.sbytes[p] = d.xf.rbytes[p] = dd_pad_msg_bytes(d.mig_caps, p, mrow);
@@ -1002,7 +1073,7 @@ struct DdImpl : IDd {
         stat_fast++;
         return true;
     }
-    int64_t stat_regrown = 0;
+    int64_t stat_regrown = 0, stat_rebuild_readbacks = 0;
 
     static void grow_keep(DevBuf<real> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
     static void grow_keep(DevBuf<emdee_lj_atom> &b, size_t keep, size_t want, hipStream_t s) { grow_keep_t(b, keep, want, s); }
@@ -1029,7 +1100,7 @@ struct DdImpl : IDd {
     // the thermostat's noise), the interior launch for the boundary half of the previous step.  Two records and two waits,
     // one hop on the critical path.
     bool lockstep_ok() const {
-        return overlap && two_streams && lockstep && !in_rebuild && dom.size() == 1 && (use_rccl || dom[0]->geo.npeers == 0);
+        return overlap && two_streams && lockstep && !in_rebuild && dom.size() == 1 && (use_rccl || mirror || dom[0]->geo.npeers == 0);
     }
     // the compute stream catches up with the halo stream (before a read-back, a rebuild, anything that is not a step)
     void join_halo() {
@@ -1363,6 +1434,7 @@ struct DdImpl : IDd {
         }
         out[2] = rb; out[3] = nrb;
         if (!dom.empty() && dom[0]->n_owned + dom[0]->n_ghost > 0) out[4] = (double)dom[0]->n_ghost / (double)(dom[0]->n_owned + dom[0]->n_ghost);
+        out[5] = (double)stat_rebuild_readbacks; out[6] = (double)stat_fast; out[7] = (double)stat_regrown;
     }
     void rebuild_stats(int64_t out[4]) override {
         out[0] = stat_fast + stat_fallback; out[1] = stat_fallback;

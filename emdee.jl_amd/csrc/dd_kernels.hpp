@@ -31,6 +31,8 @@ struct DdDev {
     int dir_bin[DD_MAX_DIRS];         // position of the direction in the send list: sorted by (destination rank, direction)
     int bin_dir[DD_MAX_DIRS];         // ... and back
     int rank_bin[DD_MAX_WORLD];       // migration: destination rank -> bin (0 = stays, 1 + peer index, -1 = not a neighbour)
+    real mig_off[DD_MAX_PEERS + 1][3]; // subtracted from the position of an atom that leaves in bin b: zero, except in the replica
+                                      // rehearsal of one rank (dd.hpp, DdImpl::mirror), where the leaver comes back in as its own image
 };
 
 // rows that travel at a rebuild
@@ -204,13 +206,15 @@ static __global__ void k_dd_map_ids(int n, const int *__restrict__ map, int *__r
 template <typename real>
 __global__ void k_dd_pack_migrants(int first, int total, const int *__restrict__ ids, const real *__restrict__ x,
                                    const real *__restrict__ v, const emdee_lj_atom *__restrict__ atoms,
-                                   const long long *__restrict__ gid, MigRow<real> *__restrict__ rows) {
+                                   const long long *__restrict__ gid, MigRow<real> *__restrict__ rows, DdDev<real> g, DdBins starts) {
     int k = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
     const int i = ids[k];
+    int bin = 1;                       // starts.lo[b] = first list position of bin b (the leavers of peer b - 1)
+    while (bin < starts.npeers && k >= starts.lo[bin + 1]) bin++;
     MigRow<real> r;
 #pragma unroll
-    for (int d = 0; d < 3; d++) { r.x[d] = x[3 * (size_t)i + d]; r.v[d] = v[3 * (size_t)i + d]; }
+    for (int d = 0; d < 3; d++) { r.x[d] = x[3 * (size_t)i + d] - g.mig_off[bin][d]; r.v[d] = v[3 * (size_t)i + d]; }
     r.hs = atoms[i].half_sigma; r.te = atoms[i].twice_sqrt_eps;
     r.gid = gid[i];
     rows[k - first] = r;
@@ -386,7 +390,7 @@ template <typename real>
 __global__ void k_dd_pack_migrants_sorted(DdCaps caps, PartView lv, const int *__restrict__ ids,
                                           const Rec<real> *__restrict__ rec, const float *__restrict__ te,
                                           const real *__restrict__ vel, size_t pitch, const long long *__restrict__ tag,
-                                          unsigned char *__restrict__ buf) {
+                                          unsigned char *__restrict__ buf, DdDev<real> g) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < caps.npeers) {
         int over = 0;
@@ -401,7 +405,7 @@ __global__ void k_dd_pack_migrants_sorted(DdCaps caps, PartView lv, const int *_
     const int i = ids[lv.start(1 + p) + slot];
     const Rec<real> a = rec[i];
     MigRow<real> r;
-    r.x[0] = a.x; r.x[1] = a.y; r.x[2] = a.z;
+    r.x[0] = a.x - g.mig_off[1 + p][0]; r.x[1] = a.y - g.mig_off[1 + p][1]; r.x[2] = a.z - g.mig_off[1 + p][2];
 #pragma unroll
     for (int d = 0; d < 3; d++) r.v[d] = vel[d * pitch + i];
     rec_params(rec, te, i, r.hs, r.te);

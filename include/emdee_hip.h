@@ -313,7 +313,10 @@ int32_t emdee_dd_rebuild_stats(emdee_dd *dd, int64_t out[4]);
 /* Where the host-side time of this process's decomposition goes, cumulative since emdee_dd_create (take differences
  * around a timed region): out[0] = wall-clock ms inside rebuilds (ownership path, exchanges, read-backs, the engines'
  * sort + list), out[1] = rebuilds (the load included), out[2] = wall-clock ms of blocking read-backs of device words,
- * out[3] = read-backs, out[4] = ghost share n_ghost / (n_owned + n_ghost) of local domain 0 as of now, out[5..7] = 0.
+ * out[3] = read-backs, out[4] = ghost share n_ghost / (n_owned + n_ghost) of local domain 0 as of now, out[5] = the read-backs
+ * among out[3] that happened INSIDE rebuilds (a rebuild in the engines' own order has one, with the build's words; the read-back
+ * of a batch's request words that asked for it is not among them), out[6] = rebuilds done in the engines' own order, out[7] =
+ * engines loaded again for room (a local matter: the state outgrew the slots its last load left).
  * The device-side phases of a step are emdee_md_kernel_time of emdee_dd_engine: 5 = fused step launches over interior
  * bricks (or all bricks, in-order form), 6 = over boundary bricks, 7 = halo (pack -> exchange -> unpack), 2 = sort + list. */
 int32_t emdee_dd_phase_times(emdee_dd *dd, double out[8]);

@@ -98,6 +98,11 @@ def test_two_ranks_over_rccl_on_one_gpu():
         assert (r["force_boundary_ms"] > 0) == (h["chosen"] == "overlapped")
         assert r["rebuilds"] >= 1 and r["rebuild_wall_ms"] > r["rebuild_device_ms"] > 0 and r["readbacks"] >= r["rebuilds"]
         assert r["readback_wall_ms"] < d["ms_per_step"] and r["force_interior_ms"] + r["force_boundary_ms"] < d["ms_per_step"]
+        # a rebuild in the engines' own order costs TWO blocking read-backs: the batch's request words and the build's words, which
+        # carry the counts of both exchanges along (round 4: three; round 2: five)
+        if r["rebuilds_in_engine_order"] == r["rebuilds"]:
+            assert r["readbacks_per_rebuild"] <= 2.0, r
+    assert any(r["rebuilds_in_engine_order"] == r["rebuilds"] for r in pr), pr
     # the two trials took 2 x (2 + 2) untimed steps: the undivided run gets them as warm-up
     one = _bench("--cells", "16", "--steps", "8", "--warmup", "12", "--no-cpu-baseline")
     assert d["energy_per_atom"]["potential"] == pytest.approx(one["energy_per_atom"]["potential"], rel=1e-9)

@@ -97,6 +97,62 @@ def test_dd_trajectory_matches_oracle(emdee, oracle, world, rebuild_every, lange
     dd.close()
 
 
+@pytest.mark.parametrize("grid,langevin,dtype", [((2, 2, 2), 0, "f64"), ((2, 1, 1), 1, "f64"), ((2, 2, 1), 0, "f64"), ((2, 2, 2), 0, "f32")])
+def test_dd_replica_rehearsal_of_one_rank_matches_the_periodic_brick(emdee, oracle, grid, langevin, dtype):
+    """One rank of a 2 x 2 x 2 (2 x 1 x 1, 2 x 2 x 1) grid on its own, every peer its own periodic image (mirror=True: the
+    messages a rank with SEVEN peers packs, sends, receives and unpacks -- migrants, padded ghost rows, the per-step halo on
+    its stream -- are all there, copied from its own send buffer): the box is then periodic with the brick's period, and the
+    run must reproduce the undivided periodic box of ONE brick.  Corner and edge directions, a peer reached in several
+    directions, atoms that leave through a face and come back in through the opposite one, rebuilds in the engine's order."""
+    E = emdee
+    pos, vel, eps, sigma, W = _global_box(E.synthetic, uniform=False)
+    vel = 1.4 * vel
+    N = pos.shape[0]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    ndt = np.float64 if dtype == "f64" else np.float32
+    dev = torch.device("cuda", 0)
+    dd = E.DomainDecomposition([g * W for g in grid], grid, E.LennardJonesModel(RC, RS), skin=SKIN, dtype=tdt, device=dev, rank=0, mirror=True)
+    dd.set_atoms_(0, E.cu(pos.astype(ndt), dev), E.cu(vel.astype(ndt), dev), E.cu(atoms, dev), torch.arange(N, dtype=torch.int64, device=dev))
+    dd.load_()
+    if langevin:
+        dd.set_langevin_(*LANGEVIN)
+    world = grid[0] * grid[1] * grid[2]
+    c = dd.counts(0)
+    assert c["n_owned"] == N and c["n_global"] == world * N and c["n_ghost"] > 0
+    nsteps = 30
+    dd.step_(13, DT, 0)
+    ph0, st0 = dd.phase_times(), dd.stats()
+    dd.step_(nsteps - 13, DT, 4)
+    ph1, st1 = dd.phase_times(), dd.stats()
+    # every rebuild of the second call ran in the engine's own order, with ONE blocking read-back inside it (the build's words
+    # carry the counts of both exchanges), and no engine had to be loaded again for room
+    n_rb = st1["rebuilds"] - st0["rebuilds"]
+    assert n_rb >= 3 and ph1["rebuilds_in_engine_order"] - ph0["rebuilds_in_engine_order"] == n_rb
+    assert ph1["rebuild_readbacks"] - ph0["rebuild_readbacks"] == n_rb and ph1["engines_regrown"] == 0
+    e1 = dd.totals()
+    orc_atoms = oracle.lj_atoms(eps, sigma)
+    p0, v0 = pos.astype(ndt).astype(np.float64), (vel.astype(ndt)).astype(np.float64)
+    if langevin:
+        ref = oracle.verlet_langevin(p0, v0, W, oracle.model(RC, RS), orc_atoms, DT, nsteps, *LANGEVIN)
+    else:
+        ref = oracle.verlet(p0, v0, W, oracle.model(RC, RS), orc_atoms, DT, nsteps)
+    gid, x, v, f = (t.cpu().numpy() for t in dd.state(0))
+    assert np.array_equal(np.sort(gid), np.arange(N))
+    xs, vs, fs = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3))
+    xs[gid], vs[gid], fs[gid] = x, v, f
+    dx = xs - ref["x"]
+    tol = 1e-9 if dtype == "f64" else 2e-3
+    assert np.abs(dx - W * np.rint(dx / W)).max() < tol
+    assert np.abs(vs - ref["v"]).max() < 10 * tol
+    assert np.abs(fs - ref["f"]).max() < (1e-6 if dtype == "f64" else 2e-2) * np.abs(ref["f"]).max()
+    # (the totals are those of the rehearsed grid: every rank holds the same)
+    assert e1[0] == pytest.approx(world * ref["epot"][-1], rel=1e-8 if dtype == "f64" else 2e-4)
+    st, rs = dd.stats(), dd.rebuild_stats()
+    assert st["rebuilds"] >= 4 and st["migrated"] > 0 and rs["count_free"] >= st["rebuilds"] - 2
+    dd.close()
+
+
 @pytest.mark.parametrize("world", [1, 4])
 def test_dd_in_order_exchange_gives_the_same_trajectory(emdee, world):
     """emdee_dd_set_overlap(0): pack, exchange, unpack and ONE launch over all bricks in order (for one domain per process
@@ -277,6 +333,55 @@ def test_full_size_box_in_eight_domains(emdee):
     assert dd.rebuild_stats()["count_free"] >= 1
     dd.close()
     torch.cuda.empty_cache()
+
+
+def test_queries_of_an_in_process_domain_are_ordered_on_the_callers_stream(emdee):
+    """The engines of an in-process decomposition run on streams of the library's own; emdee_md_nbr_list / emdee_md_get_state /
+    emdee_dd_get_state fill arrays the CALLER hands in.  The library orders those writes against the caller's context stream
+    itself (csrc/common.hpp FenceOut: two event hops, no device synchronisation, nothing in the Python binding): here torch's
+    stream is kept busy for tens of milliseconds writing a block that is then freed -- the allocator hands the same memory to
+    the query's arrays while that work is still queued -- and an 8-domain box of 1,048,576 atoms must still return complete
+    rows and the same state as a query on an idle device.  (Round 4 found rows still holding their -1 fill at 10^7 atoms and
+    fenced in Python; a C or Julia caller had the same race.)"""
+    E = emdee
+    dev = torch.device("cuda", 0)
+    pos, L = E.synthetic.fcc_positions(64)
+    N = pos.shape[0]
+    assert N == 1048576
+    vel = E.synthetic.velocities(N)
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    dd = _build(E, 8, pos, vel, atoms, L, scatter=False)
+    dd.step_(3, DT, 0)
+    torch.cuda.synchronize(dev)
+    quiet = []
+    for r in range(8):
+        eng = dd.engine(r)
+        c, nb = eng.neighbor_lists()
+        gid, x, v, f = dd.state(r)
+        torch.cuda.synchronize(dev)
+        quiet.append((c.clone(), nb.clone(), gid.clone(), x.clone(), f.clone()))
+        del c, nb, gid, x, v, f
+    torch.cuda.empty_cache()
+    m = 3072
+    b = torch.randn((m, m), dtype=torch.float64, device=dev)
+    for r in range(8):
+        eng = dd.engine(r)
+        rows = int(quiet[r][1].numel())
+        a = torch.empty(max(rows, 4 * m * m), dtype=torch.int32, device=dev)          # the block the query's arrays will come from
+        av = a[: 2 * m * m].view(torch.float64).view(m, m)
+        for _ in range(12):                                                              # ~ tens of ms of fp64 GEMMs writing into it, queued
+            torch.mm(b, b, out=av)
+        a[2 * m * m:].fill_(-7)
+        del av, a                                                                        # freed while that work is still queued
+        c, nb = eng.neighbor_lists()
+        gid, x, v, f = dd.state(r)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(c, quiet[r][0]), "row counts of domain %d changed under a busy caller stream" % r
+        assert torch.equal(nb, quiet[r][1]), "rows of domain %d changed under a busy caller stream" % r
+        assert torch.equal(gid, quiet[r][2]) and torch.equal(x, quiet[r][3]) and torch.equal(f, quiet[r][4])
+        valid = torch.arange(nb.shape[1], device=dev)[None, :] < c[:, None].long()
+        assert bool((nb[valid] >= 0).all()), "a listed entry still holds its fill"
+    dd.close()
 
 
 @pytest.mark.parametrize("config", ["fp32", "mixture_rc35"])
