@@ -155,6 +155,13 @@ struct BrickArgs {
     int nsub, sub_k;
     const int *fstart;
     int *bsub;
+    // near/far rows with the far class skipped outright (round 5 experiment, EMDEE_FAR_SKIP=1 on top of EMDEE_BUILD_NEARFAR=1):
+    // cnt[p] = total | near << 8, and while NO atom has moved delta / 2 since the build (*far_word == 0: raised like the
+    // rebuild trigger, by the launch that produced the positions, read by the next one) a row ends at its near entries -- an
+    // entry beyond r_c + delta at the build cannot be inside r_c before two atoms have moved delta / 2 each: the same sums
+    int far_skip;
+    int *far_word;
+    real thr2_near;
     const real *user_pos;      // ... read from the CALLER's array (3 x N, caller order): the engine's records hold positions wrapped
                                // into the box, and x - L rounded to fp32 is not the number the reference divides by L
 };
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
                 }
                 if (gl == G - 1) {                            // the last lane's inclusive prefixes add up to the row length
                     const unsigned total = (unsigned)(inclN + inclF);
-                    a.cnt[p] = act ? (int)min(total, ustride) : 0;
+                    a.cnt[p] = act ? (int)(min(total, ustride) | (a.far_skip ? (min((unsigned)inclN, ustride) << 8) : 0u)) : 0;
                     if (total > ustride) atomicMax(&a.flags[0], (int)total);
                 }
             }
@@ -1291,6 +1298,9 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     int bxi, byi, bzi, tile_n, n_own;
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    // (far class skipped: rows end at their near entries while nobody has moved delta / 2; the statistics always see whole rows)
+    const bool near_only = a.far_skip != 0 && MODE != BRICK_STATS && *a.far_word == 0;
+    auto row_len = [&](int c) { return a.far_skip ? (near_only ? (c >> 8) : (c & 255)) : c; };
 
     // ---- own-atom table entries first: their global loads fly while the tile is being staged --------
     // row length = cnt[p]; the build kernel wrote 0 for ghosts (they own no row and receive no force)
@@ -1301,7 +1311,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         own_p[k] = own_ti[k] = own_m[k] = 0;
         if (o < n_own) {
             brick_locate(T, o, own_ti[k], own_p[k]);
-            own_m[k] = a.cnt[own_p[k]];
+            own_m[k] = row_len(a.cnt[own_p[k]]);
         }
     }
     // ---- stage the tile: HBM -> LDS, unit stride inside each tile row, image shift applied -----------
@@ -1356,7 +1366,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {   // very dense bricks only
         int ti, p;
         brick_locate(T, o, ti, p);
-        if (EMDEE_BOUND(BS_FORCE_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (a.cnt[p] << 16) | ti);
+        if (EMDEE_BOUND(BS_FORCE_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (row_len(a.cnt[p]) << 16) | ti);
     }
     __syncthreads();
 
@@ -1569,6 +1579,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     a.rec_next[p] = r;
                     const real ex = r.x - bx, ey = r.y - by, ez = r.z - bz;
                     if (ex * ex + ey * ey + ez * ez > a.thr2) *a.trigger = 1;
+                    if (a.far_skip && ex * ex + ey * ey + ez * ez > a.thr2_near) *a.far_word = 1;
                 }
             } else if (have && gl == G - 1) {
                 if (a.user_f != nullptr || a.user_e != nullptr || a.user_w != nullptr) {
@@ -1626,7 +1637,7 @@ __global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int
         brick_locate(T, o, ti, p);
         if (a.perm[p] >= a.n_owned) continue;
         const int i = cmap ? cmap[a.perm[p]] : a.perm[p];
-        const int m = a.cnt[p];
+        const int m = a.far_skip ? (a.cnt[p] & 255) : a.cnt[p];
         counts[i] = m;
         const unsigned short *row = a.nbr + (size_t)p * a.stride;
         for (int e = 0; e < m && e < capacity; e++) {

@@ -797,7 +797,8 @@ template <typename real>
 __global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__restrict__ perm, Rec<real> *__restrict__ rec,
                              real *__restrict__ vel, const real *__restrict__ frc, const real *__restrict__ inv_mass,
                              real c, real dt, const real *__restrict__ xb, real thr2, int *__restrict__ flag,
-                             const real *__restrict__ noise, real c1, const int *__restrict__ guard = nullptr) {
+                             const real *__restrict__ noise, real c1, const int *__restrict__ guard = nullptr,
+                             int *__restrict__ far_word = nullptr, real thr2_near = (real)0) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (guard != nullptr && *guard != 0) {   // queued behind a rebuild request: do nothing and pass the request on
         if (p == 0) *flag = 1;
@@ -818,6 +819,7 @@ __global__ void k_kick_drift(int n, int n_owned, size_t pitch, const int *__rest
     rec[p] = r;
     const real dx = r.x - xb[p], dy = r.y - xb[pitch + p], dz = r.z - xb[2 * pitch + p];
     if (dx * dx + dy * dy + dz * dz > thr2) *flag = 1;
+    if (far_word && dx * dx + dy * dy + dz * dz > thr2_near) *far_word = 1;   // (brick.hpp BrickArgs::far_skip)
 }
 
 // ---- Langevin thermostat (build-defined; the reference has neither integrator nor thermostat) ----------

@@ -278,7 +278,7 @@ struct NbSystem {
         perm.ensure(m + 1); perm2.ensure(m + 1); inv_perm.ensure(m + 1); img.ensure(m + 1); img2.ensure(m + 1);
         cell_of.ensure(m + 1); cell_sorted.ensure(m + 1); order.ensure(m + 1); cnt.ensure(m + 1);
         if (use_tags) { tag.ensure(m + 1); tag2.ensure(m + 1); }
-        if (flags.ensure(16)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 16 * sizeof(int), stream()));
+        if (flags.ensure(32)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 32 * sizeof(int), stream()));
         partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
     }
 
@@ -504,6 +504,9 @@ struct NbSystem {
                     a.te4[i * 2 + j] = (real)ti * (real)tj;
                 }
         }
+        a.far_skip = far_skip_active() ? 1 : 0;
+        a.far_word = flags.ptr + 16;
+        a.thr2_near = (real)(0.25 * near_delta() * near_delta());
         a.refmath = (sizeof(real) == 4 && refmath && ref_pos != nullptr) ? 1 : 0;
         a.user_pos = ref_pos;
         a.thr2 = (real)(0.25 * skin * skin);
@@ -704,11 +707,21 @@ struct NbSystem {
     // long as the busiest lane of the wavefront -- 585 vs 584 steps/s; profiles/README.md):
     // r_near = r_c + delta (EMDEE_NEAR_DELTA, default 0.04 length units); returns the scale k of the build tile with
     // k^2 (r_list^2 - r_near^2) = 2, or 0 when switched off or the skin is too thin
+    double near_delta() const {
+        double delta = 0.04;
+        if (const char *e = std::getenv("EMDEE_NEAR_DELTA")) delta = std::atof(e);
+        return delta;
+    }
+    // the far class skipped outright while no atom has moved delta / 2 (BrickArgs::far_skip): untyped boxes without ghosts on
+    // the near/far build, rows short enough for the two counts to share cnt[p]
+    bool far_skip_active() const {
+        const char *on = std::getenv("EMDEE_FAR_SKIP");
+        return on != nullptr && std::atoi(on) != 0 && near_far_scale() > 0.0 && brick_active && !typed_active && !has_ghosts && stride < 256 && build_alg == 3 && variant == 0;
+    }
     double near_far_scale() const {
         const char *on = std::getenv("EMDEE_BUILD_NEARFAR");
         if (on == nullptr || std::atoi(on) == 0) return 0.0;
-        double delta = 0.04;
-        if (const char *e = std::getenv("EMDEE_NEAR_DELTA")) delta = std::atof(e);
+        const double delta = near_delta();
         const double rc = std::sqrt((double)model_d.rc2), rn = rc + delta;
         if (!(delta >= 0.0) || rn >= rlist - 0.05 * skin) return 0.0;
         return std::sqrt(2.0 / (rlist * rlist - rn * rn));
@@ -848,6 +861,7 @@ struct NbSystem {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             if (in_edit && !brick_active) { edit_abort = true; return; }   // (the direct kernels count atoms on the host: the caller reloads)
             if (!(kept && attempt == 0)) Zeros().add(flags.ptr, 5).run(stream());   // (a kept plan cleared them with the maxima)
+            if (std::getenv("EMDEE_FAR_SKIP")) Zeros().add(flags.ptr + 16, 1).run(stream());   // (experiment: the near word starts afresh)
             if (brick_active) {
                 nbr16.ensure(rows * stride);
                 with_brick_variant(variant, [&](auto v) {
@@ -1204,7 +1218,8 @@ struct NbSystem {
         real thr = (real)(0.5 * skin);
         hipLaunchKernelGGL((k_kick_drift<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned,
                            pitch, perm.ptr, rec.ptr, vel.ptr, frc.ptr, with_mass ? im.ptr : nullptr, (real)c, (real)dt,
-                           xb.ptr, thr * thr, trigger ? trigger : flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1, guard);
+                           xb.ptr, thr * thr, trigger ? trigger : flags.ptr + 1, lgv_on ? noise.ptr : nullptr, (real)lgv_c1, guard,
+                           far_skip_active() ? flags.ptr + 16 : (int *)nullptr, (real)(0.25 * near_delta() * near_delta()));
         if (lgv_on) lgv_step++;
     }
 
