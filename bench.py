@@ -199,10 +199,26 @@ def self_launch(args, budget=None):
                 sys.stdout.flush()
         t = threading.Thread(target=relay, daemon=True)
         t.start()
+        def emit(status):
+            """the held result line, once, with the rank group's status in it"""
+            if not held or printed:
+                return
+            ln = held[0]
+            try:
+                d = json.loads(ln)
+                d["exit_status"] = status
+                ln = json.dumps(d) + "\n"
+            except ValueError:
+                pass
+            printed.append(ln)
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+
         try:
             rc = child.wait(timeout=limit)
         except subprocess.TimeoutExpired:
             print("bench.py: the %d-rank run exceeded %.0f s and is being stopped" % (args.gpus, limit), file=sys.stderr)
+            emit(124)                                                            # a finished measurement goes out BEFORE anything is killed
             # torch.distributed.run gives every rank a process group of its own: killing the launcher's group alone would
             # orphan ranks that are stuck in a wait, with the GPUs in their hands.  Collect the launcher's descendants while
             # the parent links still exist, then stop exactly those processes.
@@ -219,23 +235,22 @@ def self_launch(args, budget=None):
             child.wait()
             rc = 124
         t.join(timeout=5.0)
-        if held:
+        if t.is_alive():
+            # a descendant that survived still holds the pipe open: stop reading (a line that arrives after this is lost, one
+            # that arrived is in `held`)
+            try:
+                child.stdout.close()
+            except (OSError, ValueError):
+                pass
+            t.join(timeout=2.0)
+        if held and not printed:
             # The measurement is complete once its line exists, whatever happens to the ranks afterwards (target-box leg,
             # teardown, a barrier): the line is kept -- but a rank group that then ends abnormally (a crash, a GPU fault, a
             # stop at the deadline) must show in the run's records, not only on stderr: top-level "exit_status".
-            ln = held[0]
-            try:
-                d = json.loads(ln)
-                d["exit_status"] = rc
-                ln = json.dumps(d) + "\n"
-            except ValueError:
-                pass
             if rc != 0:
                 print("bench.py: the rank group ended with status %d AFTER its result line was out; the line carries exit_status"
                       % rc, file=sys.stderr)
-            printed.append(ln)
-            sys.stdout.write(ln)
-            sys.stdout.flush()
+            emit(rc)
         return rc
 
     rc = run([])

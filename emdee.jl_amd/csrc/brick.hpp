@@ -1299,8 +1299,13 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     // (far class skipped: rows end at their near entries while nobody has moved delta / 2; the statistics always see whole rows)
-    const bool near_only = a.far_skip != 0 && MODE != BRICK_STATS && *a.far_word == 0;
-    auto row_len = [&](int c) { return a.far_skip ? (near_only ? (c >> 8) : (c & 255)) : c; };
+#ifdef EMDEE_EXPERIMENTS
+    const bool far_skip = a.far_skip != 0;
+#else
+    constexpr bool far_skip = false;                          // (the product library has plain rows only)
+#endif
+    const bool near_only = far_skip && MODE != BRICK_STATS && *a.far_word == 0;
+    auto row_len = [&](int c) { return far_skip ? (near_only ? (c >> 8) : (c & 255)) : c; };
 
     // ---- own-atom table entries first: their global loads fly while the tile is being staged --------
     // row length = cnt[p]; the build kernel wrote 0 for ghosts (they own no row and receive no force)
@@ -1579,7 +1584,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                     a.rec_next[p] = r;
                     const real ex = r.x - bx, ey = r.y - by, ez = r.z - bz;
                     if (ex * ex + ey * ey + ez * ez > a.thr2) *a.trigger = 1;
-                    if (a.far_skip && ex * ex + ey * ey + ez * ez > a.thr2_near) *a.far_word = 1;
+                    if (far_skip && ex * ex + ey * ey + ez * ez > a.thr2_near) *a.far_word = 1;
                 }
             } else if (have && gl == G - 1) {
                 if (a.user_f != nullptr || a.user_e != nullptr || a.user_w != nullptr) {

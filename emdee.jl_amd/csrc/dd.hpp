@@ -219,6 +219,7 @@ struct Domain {
     hipStream_t side = nullptr;          // boundary bricks: unpack + second launch of a step, concurrent with the interior launch's tail
     hipEvent_t ev_packed = nullptr, ev_done = nullptr, ev_bnd = nullptr;
     bool halo_timed = false;             // T_HALO pair of the step in flight (in-order / in-process forms)
+    bool halo_batch_timed = false;       // ... of any step of the batch in flight
     size_t halo_tk = 0;
     std::unique_ptr<MdImpl<real>> md;
     // caller-order working arrays (owned first, then ghosts for x and atoms), double-buffered across a migration
@@ -1127,7 +1128,17 @@ struct DdImpl : IDd {
         EMDEE_HIP_CHECK(hipStreamWaitEvent(d.side, d.ev_packed, 0));
         const int np = d.geo.npeers;
         const bool timed = d.sys().profiling;
+        // (the pair is closed whatever happens in between: an exchange that throws must not leave an end event that was never
+        // recorded -- every later hipEventElapsedTime of the timer would fail)
+        struct HaloPair {
+            KernelTimer *t;
+            size_t k;
+            hipStream_t s;
+            ~HaloPair() { if (t) (void)hipEventRecord(t->pairs[k].second, s); }
+            void end() { if (t) { KernelTimer *q = t; t = nullptr; q->end(k, s); } }
+        } halo_pair{nullptr, 0, d.side};
         const size_t tk = timed ? d.sys().timers[T_HALO].begin(d.side) : 0;
+        if (timed) { halo_pair.t = &d.sys().timers[T_HALO]; halo_pair.k = tk; d.halo_batch_timed = true; }
         hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(std::max(d.n_send, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
                            d.n_send, d.plan, d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr,
                            d.V(vj), d.sendbuf.ptr);
@@ -1140,7 +1151,7 @@ struct DdImpl : IDd {
         exchange();                                                        // in order on the halo stream
         hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(std::max(d.n_ghost, std::max(np, 1)), 256)), dim3(256), 0, d.stream(),
                            d.n_ghost, d.n_owned, d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
-        if (timed) d.sys().timers[T_HALO].end(tk, d.side);
+        halo_pair.end();
         d.md->current_mask = 0;
         compute(d, 2);
         EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
@@ -1155,12 +1166,19 @@ struct DdImpl : IDd {
         }
         join_halo();
         const size_t w = sizeof(real);
+        struct ClosePairs {                                        // (as in the lock-step form: no half-recorded T_HALO pair survives an exception)
+            DdImpl *dd;
+            ~ClosePairs() {
+                for (auto &pd : dd->dom)
+                    if (pd->halo_timed) { pd->halo_timed = false; (void)hipEventRecord(pd->sys().timers[T_HALO].pairs[pd->halo_tk].second, pd->stream()); }
+            }
+        } close_pairs{this};
         for (auto &pd : dom) {
             Domain<real> &d = *pd;
             const int np = d.geo.npeers;
             const int nthreads = std::max(d.n_send, std::max(np, 1));
             d.halo_timed = d.sys().profiling;
-            if (d.halo_timed) d.halo_tk = d.sys().timers[T_HALO].begin(d.stream());
+            if (d.halo_timed) { d.halo_tk = d.sys().timers[T_HALO].begin(d.stream()); d.halo_batch_timed = true; }
             hipLaunchKernelGGL((k_dd_pack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_send, d.plan,
                                d.ids.ptr, d.codes.ptr, d.geo.template device<real>(), d.sys().inv_perm.ptr, d.sys().rec.ptr, d.V(vj),
                                d.sendbuf.ptr);
@@ -1200,7 +1218,7 @@ struct DdImpl : IDd {
                 const int nthreads = std::max(d.n_ghost, std::max(d.geo.npeers, 1));
                 hipLaunchKernelGGL((k_dd_unpack_step<real>), dim3(blocks_for(nthreads, 256)), dim3(256), 0, d.stream(), d.n_ghost, d.n_owned,
                                    d.plan, d.sys().inv_perm.ptr, d.recvbuf.ptr, d.sys().rec.ptr, d.V(vj), d.G(gj));
-                if (d.halo_timed) d.sys().timers[T_HALO].end(d.halo_tk, d.stream());
+                if (d.halo_timed) { d.halo_timed = false; d.sys().timers[T_HALO].end(d.halo_tk, d.stream()); }
                 d.md->current_mask = 0;
                 compute(d, overlap ? 2 : 0);
                 if (aside) EMDEE_HIP_CHECK(hipEventRecord(d.ev_bnd, d.side));
@@ -1302,7 +1320,10 @@ struct DdImpl : IDd {
                 s++;
                 continue;
             }
-            for (auto &pd : dom) hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
+            for (auto &pd : dom) {
+                pd->halo_batch_timed = false;
+                hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
+            }
             for (int j = 0; j < B; j++) {
                 if (lgv_on) join_halo();   // (the boundary half of the previous step still reads the previous noise)
                 for (auto &pd : dom)
@@ -1339,7 +1360,7 @@ struct DdImpl : IDd {
                 if (tiled && d.sys().profiling) {
                     d.sys().timers[T_STEP].dropped += B - ran;
                     if (overlap) d.sys().timers[T_STEP_BOUNDARY].dropped += B - ran;
-                    d.sys().timers[T_HALO].dropped += B - ran;
+                    if (d.halo_batch_timed) d.sys().timers[T_HALO].dropped += B - ran;   // (only steps whose halo was timed)
                 }
                 if (!tiled && d.sys().profiling && d.sys().n_total > 0) {
                     d.sys().timers[T_FORCE].dropped += B - ran;

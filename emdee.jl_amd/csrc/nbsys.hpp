@@ -9,11 +9,33 @@
 #include <type_traits>
 
 #include "brick.hpp"
+#ifdef EMDEE_EXPERIMENTS
 #include "brick_tbuild.hpp"
+#endif
 #include "kernels.hpp"
 #include "typed.hpp"
 
 namespace emdee {
+
+// The laboratory of rounds 1-5 -- measured alternatives that lost and the ablation switches that measured them -- compiles
+// only under `make EXPERIMENTS=1` (-> libemdee_hip_exp.so).  The product library carries none of it: no experiment kernel is
+// instantiated, and an experiment switch found in the environment is REFUSED with a message when an engine is created, not
+// ignored (a run that believes it is measuring a variant must not silently measure the default).
+#ifdef EMDEE_EXPERIMENTS
+static inline const char *exp_env(const char *name) { return std::getenv(name); }
+static inline void refuse_experiment_switches() {}
+#else
+static inline const char *exp_env(const char *) { return nullptr; }
+static inline void refuse_experiment_switches() {
+    static const char *const gone[] = {"EMDEE_DEBUG_RC2_SCALE", "EMDEE_TBUILD", "EMDEE_BUILD4", "EMDEE_BUILD_ALG", "EMDEE_BUILD_CHUNKED",
+        "EMDEE_BUILD_STRIDED", "EMDEE_NO_BRICK_TABLES", "EMDEE_NO_PREMUL", "EMDEE_BUILD_NEARFAR", "EMDEE_NEAR_DELTA", "EMDEE_FAR_SKIP",
+        "EMDEE_PLAN_MAXIMA", "EMDEE_PLAN_SYNC", "EMDEE_STRIDE", "EMDEE_BRICK_VARIANT"};
+    for (const char *name : gone)
+        EMDEE_REQUIRE(std::getenv(name) == nullptr, EMDEE_ERR_INVALID,
+                      "%s is an experiment switch: this libemdee_hip.so was built without them (make -C emdee.jl_amd/csrc EXPERIMENTS=1 builds "
+                      "libemdee_hip_exp.so, selected with EMDEE_HIP_LIB)", name);
+}
+#endif
 
 // T_STEP: every fused step launch but the boundary-brick halves of a decomposed step, which go to T_STEP_BOUNDARY (emdee_md_kernel_time(4)
 // reports the two together, 5 and 6 one each); T_HALO: pack -> exchange -> unpack of a decomposed step, on the stream they run on
@@ -73,12 +95,14 @@ template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static c
 template <class F>
 static inline void with_brick_variant(int v, F &&f) {
     switch (v) {
+#ifdef EMDEE_EXPERIMENTS                                   // (brick shapes / lanes per atom of the tuning sweeps, EMDEE_BRICK_VARIANT)
         case 1: f(BrickVariant<1>{}); break;
         case 2: f(BrickVariant<2>{}); break;
         case 3: f(BrickVariant<3>{}); break;
         case 4: f(BrickVariant<4>{}); break;
         case 5: f(BrickVariant<5>{}); break;
         case 6: f(BrickVariant<6>{}); break;
+#endif
         case 7: f(BrickVariant<7>{}); break;
         case 8: f(BrickVariant<8>{}); break;
         default: f(BrickVariant<0>{}); break;
@@ -124,8 +148,8 @@ struct NbSystem {
     // boxes.  Measured in round 4 and left OFF (EMDEE_TBUILD=1 switches it on): same neighbour set, 2.63 ms per build at 10^7
     // atoms against k_brick_build's 1.90 (profiles/r04/tbuild_*.txt).  tbuild_blocked: a cell of this state has more candidates
     // than the kernel's registers hold (it raised flags[3]) -- until the next load
-    bool tbuild_enabled = std::getenv("EMDEE_TBUILD") != nullptr && std::atoi(std::getenv("EMDEE_TBUILD")) != 0 &&
-                          std::getenv("EMDEE_BUILD_ALG") == nullptr && std::getenv("EMDEE_BUILD_NEARFAR") == nullptr;
+    bool tbuild_enabled = exp_env("EMDEE_TBUILD") != nullptr && std::atoi(exp_env("EMDEE_TBUILD")) != 0 &&
+                          exp_env("EMDEE_BUILD_ALG") == nullptr && exp_env("EMDEE_BUILD_NEARFAR") == nullptr;
     bool tbuild_blocked = false;
     // Four lanes per atom in the round-robin build (round 4; EMDEE_BUILD4=1 switches it on): 16 atoms per wavefront share what
     // is paid once per atom and wavefront-round (row bookkeeping, trip counts, prefix: 400 of ~960 instructions per atom and lane
@@ -135,12 +159,19 @@ struct NbSystem {
     // s_waitcnt for 42-48 % of their lifetime, and doubling the candidate LDS reads costs only 12 % (profiles/r04/
     // tbuild_transposed_build.txt): dependent-chain latency, which the dealing does not change.  Off by default.  A lane's share of a tile row must fit a 16-bit field (64 slots per row): the x sub-bins
     // see to that in a fluid; the kernel reports a wider row in flags[4] and the state goes on with 8 lanes.
-    bool build4_enabled = std::getenv("EMDEE_BUILD4") != nullptr && std::atoi(std::getenv("EMDEE_BUILD4")) != 0;
+    bool build4_enabled = exp_env("EMDEE_BUILD4") != nullptr && std::atoi(exp_env("EMDEE_BUILD4")) != 0;
     bool build4_blocked = false;
+    bool field16_blocked = false;         // a 16-bit hit field overflowed under a plan that should have ruled it out: 32-bit fields until the next load
     static constexpr int B4_THREADS = 768, B4_G = 4;
     static constexpr int TB_NPAIR = 5;    // 640 candidates per own cell (27 cells of 17.6 atoms at rho* = 0.8, r_list = 2.8: 475)
     template <class V>
-    bool tbuild_active() const { return tbuild_enabled && !tbuild_blocked && !typed_active && std::is_same<V, BrickVariant<0>>::value; }
+    bool tbuild_active() const {
+#ifdef EMDEE_EXPERIMENTS
+        return tbuild_enabled && !tbuild_blocked && !typed_active && std::is_same<V, BrickVariant<0>>::value;
+#else
+        return false;
+#endif
+    }
     size_t lds_bytes = 0, lds_build_bytes = 0;
     float build_margin = 0.f;
 
@@ -170,7 +201,7 @@ struct NbSystem {
     int nt = 1;
     // untyped boxes on the brick path: a cell's atoms ordered by quarter along x (kernels.hpp XSubBin), digit = cell * nsub + quarter
     int nsub = 1;
-    bool subbins_enabled = std::getenv("EMDEE_NO_SUBBINS") == nullptr && std::getenv("EMDEE_NO_BRICK_TABLES") == nullptr;
+    bool subbins_enabled = std::getenv("EMDEE_NO_SUBBINS") == nullptr && exp_env("EMDEE_NO_BRICK_TABLES") == nullptr;
     int digits() const { return nt > 1 ? nt : nsub; }
     DevBuf<int> bsub;
     bool typed_enabled = std::getenv("EMDEE_NO_TYPED") == nullptr;
@@ -184,12 +215,13 @@ struct NbSystem {
     Scanner scanner;
 
     NbSystem() {
+        refuse_experiment_switches();
         if (const char *e = std::getenv("EMDEE_PATH")) path = (std::string(e) == "direct") ? PATH_DIRECT : PATH_BRICK;
-        if (const char *e = std::getenv("EMDEE_BRICK_VARIANT")) {
+        if (const char *e = exp_env("EMDEE_BRICK_VARIANT")) {
             variant = std::max(0, std::min(BRICK_VARIANTS - 1, std::atoi(e)));
             variant_forced = true;
         }
-        if (const char *e = std::getenv("EMDEE_BUILD_ALG")) { force_build1 = std::atoi(e) == 1; if (std::atoi(e) == 2) build_alg_pref = 2; }
+        if (const char *e = exp_env("EMDEE_BUILD_ALG")) { force_build1 = std::atoi(e) == 1; if (std::atoi(e) == 2) build_alg_pref = 2; }
         if (const char *e = std::getenv("EMDEE_RUN_AHEAD")) run_ahead = std::max(1, std::min(RUN_AHEAD, std::atoi(e)));
     }
 
@@ -481,7 +513,7 @@ struct NbSystem {
             a.nf_scale = k > 0.0 ? (float)k : 1.f;
             a.nf_scale2 = a.nf_scale * a.nf_scale;     // (the square of the fp32 scale the tile really gets)
         }
-        if (const char *dbg = std::getenv("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only
+        if (const char *dbg = exp_env("EMDEE_DEBUG_RC2_SCALE")) a.model.rc2 = (real)(std::atof(dbg) * (double)model.rc2);   // ablation only (EXPERIMENTS builds)
         a.frc = frc.ptr; a.en = en.ptr; a.vir = vir.ptr; a.stats = stats.ptr;
         a.phase = phase;   // only force launches are phased; build and stats always cover every brick
         a.vel = vel.ptr; a.vel_next = vel2.ptr; a.xb = xb.ptr; a.inv_mass = with_mass ? im.ptr : nullptr; a.rec_next = rec2.ptr;
@@ -651,8 +683,11 @@ struct NbSystem {
                 // (a CU holds three workgroups only up to ~50,000 B each, not 160 KB / 3: measured in round 2 by padding the launch)
                 constexpr size_t USABLE = 150000;
                 auto per_cu = [&](int tc) {
-                    const size_t b = tbuild_active<V>() ? brick_tbuild_lds_bytes<S, V::THREADS, TB_NPAIR>(tc, own_cap, st)
-                                                        : brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB, nsub),
+                    size_t b = brick_build_lds_bytes<S, V::THREADS>(tc, own_cap, st, V::GB, nsub);
+#ifdef EMDEE_EXPERIMENTS
+                    if (tbuild_active<V>()) b = brick_tbuild_lds_bytes<S, V::THREADS, TB_NPAIR>(tc, own_cap, st);
+#endif
+                    const size_t
                                  f = brick_force_lds_bytes<real, S, V::THREADS>(tc, own_cap);
                     return (int)(USABLE / std::max<size_t>(b, 1)) * 16 + (int)(USABLE / std::max<size_t>(f, 1));
                 };
@@ -662,7 +697,7 @@ struct NbSystem {
             if (std::getenv("EMDEE_DEBUG_PLAN"))
                 std::fprintf(stderr, "emdee plan: bricks %d x %d x %d, tile_cap %d (max %d), own_cap %d (max %d), max 3-cell span %d, x sub-bins %d K %d\n", bgrid.nb[0],
                              bgrid.nb[1], bgrid.nb[2], tile_cap, max_tile, own_cap, max_own, max_span3, nsub, sub_k());
-            build_alg = (!force_build1 && (V::GB == 8 || V::GB == 16) && plan_span3 <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
+            build_alg = (!force_build1 && !field16_blocked && (V::GB == 8 || V::GB == 16) && plan_span3 <= BUILD2_FIELD * V::GB) ? build_alg_pref : 1;
             // crowded tile rows (long cutoffs): the same build with one 32-bit hit field per row
             if (build_alg == 1 && !force_build1 && build_alg_pref == 3 && (V::GB == 8 || V::GB == 16) && plan_span3 <= 32 * V::GB) build_alg = 5;
             if (build_alg == 1) plan_span3 = 1 << 30;               // the ballot build has no limit
@@ -709,17 +744,17 @@ struct NbSystem {
     // k^2 (r_list^2 - r_near^2) = 2, or 0 when switched off or the skin is too thin
     double near_delta() const {
         double delta = 0.04;
-        if (const char *e = std::getenv("EMDEE_NEAR_DELTA")) delta = std::atof(e);
+        if (const char *e = exp_env("EMDEE_NEAR_DELTA")) delta = std::atof(e);
         return delta;
     }
     // the far class skipped outright while no atom has moved delta / 2 (BrickArgs::far_skip): untyped boxes without ghosts on
     // the near/far build, rows short enough for the two counts to share cnt[p]
     bool far_skip_active() const {
-        const char *on = std::getenv("EMDEE_FAR_SKIP");
+        const char *on = exp_env("EMDEE_FAR_SKIP");
         return on != nullptr && std::atoi(on) != 0 && near_far_scale() > 0.0 && brick_active && !typed_active && !has_ghosts && stride < 256 && build_alg == 3 && variant == 0;
     }
     double near_far_scale() const {
-        const char *on = std::getenv("EMDEE_BUILD_NEARFAR");
+        const char *on = exp_env("EMDEE_BUILD_NEARFAR");
         if (on == nullptr || std::atoi(on) == 0) return 0.0;
         const double delta = near_delta();
         const double rc = std::sqrt((double)model_d.rc2), rn = rc + delta;
@@ -732,7 +767,9 @@ struct NbSystem {
         with_brick_variant(variant, [&](auto v) {
             using V = decltype(v);
             ok = brick_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, nsub) <= LDS_LIMIT;
+#ifdef EMDEE_EXPERIMENTS
             if (tbuild_active<V>()) ok = brick_tbuild_lds_bytes<typename V::Shape, V::THREADS, TB_NPAIR>(tile_cap, own_cap, stride) <= LDS_LIMIT;
+#endif
             if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
         });
         return ok;
@@ -759,7 +796,7 @@ struct NbSystem {
         // the build kernel's LDS (fp32 tile + tables + one row buffer per lane group) must fit as well: very dense or
         // very inhomogeneous boxes with a long cutoff fall back to the direct (global-gather) kernels
         if (brick_active && !build_fits_lds()) brick_active = false;
-        idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !std::getenv("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
+        idx_shift = (brick_active && variant == 0 && uniform_atoms && tile_cap <= SOA_SLOTS && !exp_env("EMDEE_NO_PREMUL")) ? PLANE_SHIFT : 0;
         // two species: the typed kernels (typed.hpp), if the tile fits their coordinate planes, no three cells of a tile row hold
         // more atoms of one species than the 16-bit hit fields of their build take, and both kernels fit LDS
         typed_active = false;
@@ -820,7 +857,7 @@ struct NbSystem {
     int plan_nt = 1;
     bool typed_blocked = false;           // this state's rows outgrew the typed build (until the next load)
     bool typed_stride = false;            // the stride already includes the typed rows' segment padding
-    bool maxima_from_tables = std::getenv("EMDEE_PLAN_MAXIMA") != nullptr && std::string(std::getenv("EMDEE_PLAN_MAXIMA")) == "tables";
+    bool maxima_from_tables = exp_env("EMDEE_PLAN_MAXIMA") != nullptr && std::string(exp_env("EMDEE_PLAN_MAXIMA")) == "tables";
 
     void build_list() {
         const int n = n_total;
@@ -831,7 +868,7 @@ struct NbSystem {
             // melt 91): rounded up to whole lane-major blocks below, 96 entries there.  A longer row grows the stride and
             // builds again.  (128 instead of 96 costs 2 % of the step: 33 % more bytes flushed per build, rows 256 B apart)
             stride = (int)((expect * 1.15 + 8.0) / 16.0 + 1.0) * 16;
-            if (const char *e = std::getenv("EMDEE_STRIDE")) stride = std::max(16, std::atoi(e));   // tuning: first guess of the row stride
+            if (const char *e = exp_env("EMDEE_STRIDE")) stride = std::max(16, std::atoi(e));   // tuning: first guess of the row stride
             typed_stride = false;
         }
         btab_valid = false;
@@ -840,7 +877,7 @@ struct NbSystem {
         // populations come back with the build's overflow words -- ONE blocking read-back per rebuild instead of two.
         // (inside resort_edit n is an upper bound: the plan is compared with the number of atoms before the edit)
         const int np = in_edit ? edit_n_plan : n;
-        bool kept = plan_valid && !std::getenv("EMDEE_PLAN_SYNC") && !std::getenv("EMDEE_NO_BRICK_TABLES") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
+        bool kept = plan_valid && !exp_env("EMDEE_PLAN_SYNC") && !exp_env("EMDEE_NO_BRICK_TABLES") && path == PATH_BRICK && n > 0 && plan_M[0] == grid.M[0] &&
                     plan_M[1] == grid.M[1] && plan_M[2] == grid.M[2] && plan_n <= np + np / 8 && np <= plan_n + plan_n / 8 &&
                     plan_uniform == uniform_atoms && plan_nt == nt;
         if (kept) {
@@ -860,8 +897,9 @@ struct NbSystem {
         for (int attempt = 0; attempt < 6; attempt++) {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             if (in_edit && !brick_active) { edit_abort = true; return; }   // (the direct kernels count atoms on the host: the caller reloads)
+            bool launched4 = false;
             if (!(kept && attempt == 0)) Zeros().add(flags.ptr, 5).run(stream());   // (a kept plan cleared them with the maxima)
-            if (std::getenv("EMDEE_FAR_SKIP")) Zeros().add(flags.ptr + 16, 1).run(stream());   // (experiment: the near word starts afresh)
+            if (exp_env("EMDEE_FAR_SKIP")) Zeros().add(flags.ptr + 16, 1).run(stream());   // (experiment: the near word starts afresh)
             if (brick_active) {
                 nbr16.ensure(rows * stride);
                 with_brick_variant(variant, [&](auto v) {
@@ -884,7 +922,7 @@ struct NbSystem {
                             return;
                         }
                     }
-                    if (!btab_valid && !std::getenv("EMDEE_NO_BRICK_TABLES")) {
+                    if (!btab_valid && !exp_env("EMDEE_NO_BRICK_TABLES")) {
                         // tables of every brick, once per rebuild; the build and every force launch copy them in
                         // (the image depends on the brick shape only: a small workgroup writes it)
                         constexpr int TT = V::Shape::NTC <= 128 ? 128 : 256;
@@ -900,6 +938,7 @@ struct NbSystem {
                                            BT::bytes(0), stream(), ta);
                         btab_valid = true;
                     }
+#ifdef EMDEE_EXPERIMENTS
                     if constexpr (std::is_same<V, BrickVariant<0>>::value) {
                         if (tbuild_active<V>()) {
                             auto tk = k_brick_build_t<real, typename V::Shape, V::THREADS, V::G, TB_NPAIR>;
@@ -909,17 +948,25 @@ struct NbSystem {
                             return;
                         }
                     }
+#endif
                     auto kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 1, V::G>;
                     if constexpr (V::GB == 8 || V::GB == 16) {
+#ifdef EMDEE_EXPERIMENTS
                         if (build_alg == 2) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 2, V::G>;
+#endif
                         if (build_alg == 3) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 3, V::G>;
                         if (build_alg == 5) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 5, V::G>;
                         // round-robin candidates (brick.hpp): when the force kernels read plane values or 16-byte records with 4 lanes per atom
-                        if constexpr (V::G == 4 || (V::G == 8 && sizeof(real) == 4)) {
-                            // (8 lanes per atom on 16-byte records: EMDEE_BUILD_STRIDED=1 only, an experiment)
-                            const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !std::getenv("EMDEE_BUILD_CHUNKED") &&
-                                                    (V::G == 4 || std::getenv("EMDEE_BUILD_STRIDED") != nullptr);
+#ifdef EMDEE_EXPERIMENTS
+                        constexpr bool STRIDED_G8 = sizeof(real) == 4;   // (8 lanes per atom on 16-byte records: EMDEE_BUILD_STRIDED=1 only)
+#else
+                        constexpr bool STRIDED_G8 = false;
+#endif
+                        if constexpr (V::G == 4 || (V::G == 8 && STRIDED_G8)) {
+                            const bool strided_ok = (sizeof(real) == 4 || idx_shift != 0) && !exp_env("EMDEE_BUILD_CHUNKED") &&
+                                                    (V::G == 4 || exp_env("EMDEE_BUILD_STRIDED") != nullptr);
                             if (build_alg == 3 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 13, V::G>;
+#ifdef EMDEE_EXPERIMENTS
                             if constexpr (std::is_same<V, BrickVariant<0>>::value) {
                                 if (build_alg == 3 && strided_ok && nsub == 4 && build4_enabled && !build4_blocked && near_far_scale() <= 0.0) {
                                     auto k4 = k_brick_build<real, typename V::Shape, B4_THREADS, B4_G, 13, V::G>;
@@ -927,6 +974,7 @@ struct NbSystem {
                                     if (lds4 <= LDS_LIMIT) {
                                         lds_build_bytes = lds4;
                                         allow_big_lds(k4, lds4);
+                                        launched4 = true;
                                         hipLaunchKernelGGL(k4, dim3(bgrid.per_xcd * NXCD), dim3(B4_THREADS), lds4, stream(), brick_args());
                                         return;
                                     }
@@ -934,6 +982,7 @@ struct NbSystem {
                             }
                             // ... and near entries first (brick.hpp ALG 23), when the skin leaves room for a near radius
                             if (build_alg == 3 && strided_ok && near_far_scale() > 0.0) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 23, V::G>;
+#endif
                             if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
                         }
                     }
@@ -965,10 +1014,20 @@ struct NbSystem {
                 make_plan();
                 continue;
             }
-            if (brick_active && ctx->host_flags[4] != 0 && !build4_blocked) {
-                // a tile row wider than 4 lanes x 16-bit fields take: this state goes on with 8 lanes per atom in the build
-                build4_blocked = true;
-                if (std::getenv("EMDEE_DEBUG_PLAN")) std::fprintf(stderr, "emdee plan: a tile row needs %d trips of 4 lanes (> 16): the build goes on with 8 lanes per atom\n", ctx->host_flags[4]);
+            if (brick_active && ctx->host_flags[4] != 0) {
+                // A lane's share of a tile row did not fit its 16-bit hit field.  The 4-lane build (an experiment) sees that
+                // when the x sub-bins do not keep a row within 64 slots: this state goes on with 8 lanes per atom.  The default
+                // builds cannot (the plan's widest 3-cell run is what picked the field): should they ever, the list is NOT
+                // taken -- this state goes on with 32-bit fields.
+                if (launched4) {
+                    build4_blocked = true;
+                    if (std::getenv("EMDEE_DEBUG_PLAN")) std::fprintf(stderr, "emdee plan: a tile row needs %d trips of 4 lanes (> 16): the build goes on with 8 lanes per atom\n", ctx->host_flags[4]);
+                    continue;
+                }
+                EMDEE_REQUIRE(!field16_blocked, EMDEE_ERR_OVERFLOW, "neighbour build: a lane's share of a tile row (%d) overflows its hit field", ctx->host_flags[4]);
+                field16_blocked = true;
+                kept = false; plan_valid = false; btab_valid = false;
+                make_plan();
                 continue;
             }
             if (brick_active && ctx->host_flags[3] != 0 && !tbuild_blocked) {
@@ -1036,6 +1095,7 @@ struct NbSystem {
         typed_blocked = false;
         tbuild_blocked = false;
         build4_blocked = false;
+        field16_blocked = false;
         if (uniform_known >= 0 && n_total > 0) {
             uniform_atoms = uniform_known == 1;
             // (decomposed runs: the two species every domain agreed on at the first load, emdee_dd_load)
@@ -1353,12 +1413,10 @@ struct NbSystem {
         memcpy(&first.half_sigma, &ctx->host_flags[14], 4);
         memcpy(&first.twice_sqrt_eps, &ctx->host_flags[15], 4);
         uniform_atoms = false;
+        uni_first = first;                                   // (what a decomposition votes on, and what the next load starts from)
         if (ctx->host_flags[5] == 0 && !std::getenv("EMDEE_NO_UNIFORM") && first.half_sigma > 0.f && std::isfinite(first.half_sigma)) {
             uniform_atoms = true;
-            const real sg = (real)first.half_sigma + (real)first.half_sigma;
-            uni_sigma = (double)sg;
-            uni_sigma2 = (double)(sg * sg);
-            uni_e4 = (double)((real)first.twice_sqrt_eps * (real)first.twice_sqrt_eps);
+            set_uniform_constants(first);
         }
         return ctx->host_flags[1] != 0;
     }

@@ -51,8 +51,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB)
+        # (EMDEE_ORACLE_LIB: another build of the same sources -- `make -C oracle asan`, tests/test_oracle.py::test_oracle_under_asan)
+        path = os.environ.get("EMDEE_ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB
+        L = C.CDLL(path)
         p = C.c_void_p
         L.orc_model_f32.argtypes = [C.c_double, C.c_double, C.POINTER(Model32)]
         L.orc_model_f64.argtypes = [C.c_double, C.c_double, C.POINTER(Model64)]

@@ -120,46 +120,6 @@ def test_neighbour_set_with_x_sub_bins(emdee, oracle, dev, case, monkeypatch, ca
     assert np.abs(fa - fb).max() <= (1e-10 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb).max())
 
 
-@pytest.mark.parametrize("case", ["fcc_jitter_f64", "random_gas_f64", "fcc_jitter_f32"])
-def test_neighbour_set_of_the_transposed_build(emdee, oracle, dev, case, monkeypatch):
-    """EMDEE_TBUILD=1: k_brick_build_t (brick_tbuild.hpp: the candidates of an own cell in the lanes' registers, its atoms in
-    the loop, hits stored at base + v_mbcnt) -- measured in round 4 and left off (profiles/r04/tbuild_transposed_build.txt), but
-    it is in the library: same neighbour SET as the default build and, in fp64, as the oracle; same forces to rounding."""
-    E = emdee
-    rng = np.random.default_rng(23)
-    rc, rs, skin = 2.5, 2.0, 0.3
-    dtype = np.float32 if case.endswith("f32") else np.float64
-    if case.startswith("fcc"):
-        x, L = E.synthetic.fcc_positions(14)
-        x = x + rng.normal(0.0, 0.1, size=x.shape)
-    else:
-        L, N = 9 * 2.8, 14000
-        x = rng.uniform(0.0, L, size=(N, 3))
-    x = x.astype(dtype)
-    N = x.shape[0]
-    tdt = torch.float64 if dtype == np.float64 else torch.float32
-    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
-    out = {}
-    for name in ("default", "transposed"):
-        if name == "transposed":
-            monkeypatch.setenv("EMDEE_TBUILD", "1")
-        tiles = E.nonbonded_computation_tiles(N, skin=skin)
-        f = torch.zeros((N, 3), dtype=tdt, device=dev)
-        E.compute_nonbonded_(f, None, None, E.cu(x, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(E.FORCES))
-        out[name] = (_rows(*tiles.neighbor_lists()), f.cpu().numpy())
-    monkeypatch.delenv("EMDEE_TBUILD")
-    got, ref = out["transposed"][0], out["default"][0]
-    assert sum(len(r) for r in got) > 10 * N
-    for i in range(N):
-        assert np.array_equal(got[i], ref[i]), "row %d differs from the default build" % i
-    if dtype == np.float64:
-        want = _oracle_rows(oracle, x, L, rc + skin)
-        for i in range(N):
-            assert np.array_equal(got[i], want[i]), "row %d differs from the oracle" % i
-    fa, fb = out["transposed"][1], out["default"][1]
-    finite = np.isfinite(fb).all(axis=1)                              # (a random gas has pairs at r -> 0)
-    assert np.abs(fa[finite] - fb[finite]).max() <= (1e-9 if dtype == np.float64 else 2e-3) * max(1.0, np.abs(fb[finite]).max())
-
 
 def test_posted_read_backs_and_copies_give_the_same_run(emdee, dev, monkeypatch):
     """The small blocking read-backs (rebuild requests of a batch of queued steps, the build's overflow words) are posted by a
@@ -410,3 +370,77 @@ def test_two_species_boxes_take_the_typed_kernels(emdee, oracle, dev, capfd, mon
         want = _oracle_rows(oracle, pos, L, rc + 0.3)
         for i in range(N):
             assert np.array_equal(a["rows"][i], want[i]), "row %d differs from the oracle's" % i
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("species", ["uniform", "five_species"])
+def test_operator_calls_that_outrun_their_list(emdee, oracle, dev, monkeypatch, dtype, species):
+    """compute_nonbonded_ on a kept handle, tiled box with x sub-bins (32,000 atoms): a call whose positions have moved past
+    skin / 2 re-sorts from the records its own refresh pass has just written (round 4, csrc/impl.hpp NbrImpl::compute) -- against
+    EMDEE_OPERATOR_RELOAD=1, which loads afresh from the caller's arrays as rounds 1-3 did.  Several such calls, with the LJAtom
+    array edited in between (a uniform box that gets a new sigma; a five-species box whose species are dealt again): the
+    same builds counter, the same neighbour rows, forces against the fp64 oracle, in both forms."""
+    E = emdee
+    rng = np.random.default_rng(41)
+    rc, rs, skin = 2.5, 2.0, 0.3
+    ndt = np.float64 if dtype == "f64" else np.float32
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    x0, L = E.synthetic.fcc_positions(20)
+    N = x0.shape[0]
+    x0 = x0 + rng.normal(0.0, 0.05, size=x0.shape)
+
+    def make_atoms(seed, sigma_uniform):
+        if species == "uniform":
+            return np.full(N, 1.0), np.full(N, sigma_uniform)
+        r = np.random.default_rng(seed)
+        kind = r.integers(0, 5, N)
+        return np.array([1.0, 0.8, 1.2, 0.5, 0.9])[kind], np.array([1.0, 0.95, 1.03, 0.9, 0.97])[kind]
+
+    # (move amplitude, new LJAtom array or None)
+    script = [(0.0, None), (0.05, None), (0.4, None), (0.3, (7, 1.04)), (0.02, None), (0.35, (9, 0.98)), (0.3, None)]
+    runs = {}
+    for form in ("resort", "reload"):
+        if form == "reload":
+            monkeypatch.setenv("EMDEE_OPERATOR_RELOAD", "1")
+        mover = np.random.default_rng(5)
+        x = x0.copy()
+        eps, sigma = make_atoms(3, 1.0)
+        tiles = E.nonbonded_computation_tiles(N, skin=skin)
+        builds, out = [], []
+        for amp, edit in script:
+            step = mover.uniform(-1, 1, size=x.shape)
+            step /= np.linalg.norm(step, axis=1, keepdims=True)
+            x = x + amp * step
+            if edit is not None:
+                eps, sigma = make_atoms(*edit)
+            atoms = E.lennard_jones_atoms(eps, sigma)
+            xs = x.astype(ndt)
+            f = torch.zeros((N, 3), dtype=tdt, device=dev)
+            e = torch.zeros(N, dtype=tdt, device=dev)
+            E.compute_nonbonded_(f, e, None, E.cu(xs, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(E.FORCES | E.ENERGIES))
+            builds.append(tiles.stats()["builds"])
+            out.append((f.cpu().numpy().astype(np.float64), e.cpu().numpy().astype(np.float64), _rows(*tiles.neighbor_lists()), xs.astype(np.float64), atoms))
+        runs[form] = (builds, out)
+    monkeypatch.delenv("EMDEE_OPERATOR_RELOAD")
+    assert runs["resort"][0] == runs["reload"][0] == [1, 1, 2, 3, 3, 4, 5], runs["resort"][0]
+    om = oracle.model(rc, rs)
+    for k in range(len(script)):
+        fa, ea, ra, xs, atoms = runs["resort"][1][k]
+        fb, eb, rb, _, _ = runs["reload"][1][k]
+        f0, e0, _ = oracle.nonbonded_cells(xs, L, om, atoms)
+        scale = np.abs(f0).max()
+        tol = 1e-9 if dtype == "f64" else 2e-4
+        assert np.abs(fa - f0).max() <= tol * scale and np.abs(fb - f0).max() <= tol * scale, (k, np.abs(fa - f0).max() / scale)
+        assert np.abs(ea - e0).max() <= tol * np.abs(e0).max() and np.abs(eb - e0).max() <= tol * np.abs(e0).max()
+        assert np.abs(fa - fb).max() <= (1e-12 if dtype == "f64" else 1e-4) * scale
+        differing = sum(0 if np.array_equal(a, b) else 1 for a, b in zip(ra, rb))
+        assert differing <= (0 if dtype == "f64" else 4), "call %d: %d rows differ between the re-sort and the reload" % (k, differing)
+        if dtype == "f64" and builds_changed(runs["resort"][0], k):
+            want = _oracle_rows(oracle, xs, L, rc + skin)
+            for i in range(N):
+                assert np.array_equal(ra[i], want[i]), "call %d row %d differs from the oracle" % (k, i)
+
+
+def builds_changed(builds, k):
+    return k == 0 or builds[k] != builds[k - 1]
+

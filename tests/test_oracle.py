@@ -307,3 +307,24 @@ def test_langevin_generator_and_thermostatted_steps_match_independent_restatemen
     a = oracle.verlet_langevin(pos, vel, L, mdl, atoms, 0.005, 5, 0.0, 0.7, 1)
     b = oracle.verlet(pos, vel, L, mdl, atoms, 0.005, 5)
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["v"], b["v"])
+
+
+def test_oracle_under_asan():
+    """The checker itself under AddressSanitizer + UBSan (`make -C oracle asan`; GPU sanitizers are not available on the pool,
+    SURVEY.md section 5): this file once more in a child process that loads libemdee_oracle_asan.so -- an out-of-bounds
+    read in the cell-list restatement or a signed overflow in the Langevin counters would end the child."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "asan"])
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    assert os.path.isabs(asan_rt) and os.path.exists(asan_rt), asan_rt
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1",
+               EMDEE_ORACLE_LIB=os.path.join(root, "oracle", "libemdee_oracle_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_oracle.py", "-x", "-q", "-p", "no:cacheprovider", "-k", "not under_asan"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, \
+        r.stdout[-800:] + r.stderr[-1200:]
