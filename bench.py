@@ -305,6 +305,31 @@ def traffic_floor(atoms, word_bytes, rc, density=0.8):
     return atoms * (21.0 * word_bytes + 2.0 * nbar)
 
 
+def load_valu_entries():
+    """profiles/valu.json: the VALU issue floor of the step kernel (SQ counter passes, profiles/pmc_valu.sh), one entry per
+    configuration like traffic.json"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu.json")) as fh:
+            data = json.load(fh)
+    except (OSError, ValueError):
+        return []
+    return data.get("entries", []) if isinstance(data, dict) else []
+
+
+def pick_valu(entries, atoms, dtype, rc, mixture):
+    """The entry measured on EXACTLY this configuration (atoms per GPU, arithmetic type, cutoff, one or two species), or None:
+    an instruction count of the single-species fp64 kernel says nothing about the fp32 or the two-species one."""
+    for e in entries:
+        try:
+            same = (int(e["atoms"]) == int(atoms) and e["dtype"] == dtype and abs(float(e.get("rc", 2.5)) - float(rc)) < 1e-9
+                    and bool(e.get("mixture", False)) == bool(mixture))
+        except (KeyError, TypeError, ValueError):
+            continue
+        if same:
+            return e if e.get("issue_floor_ms") and e.get("valu_insts_per_launch") else None
+    return None
+
+
 def pick_traffic(entries, atoms, dtype, rc, mixture, floor_bytes):
     """The entry measured on EXACTLY this configuration -- atoms per GPU, arithmetic type, cutoff, one or two species -- or
     None: a line never carries another configuration's traffic (round 3 attached the single-species figure to the mixture
@@ -700,21 +725,17 @@ def main():
             out["roofline"]["traffic_source"] = t.get("source")
         # the same kernel against the limit that actually binds it in fp64 ("report VALU
         # utilisation next to GB/s"): instruction counts from the committed SQ counter pass, live duration
-        valu = os.path.join(ROOT, "profiles", "valu.json")
-        if os.path.exists(valu) and not args.mixture:
-            try:
-                with open(valu) as fh:
-                    t = json.load(fh)
-                if t.get("atoms") == N_rank and t.get("dtype") == out["dtype"] and force_avg_s > 0:
-                    out["valu_issue"] = {"kernel": "lj_force_nbr (fused)", "floor_ms": t["issue_floor_ms"],
-                                         "avg_launch_ms": force_avg_s * 1e3, "frac": t["issue_floor_ms"] / (force_avg_s * 1e3),
-                                         "valu_insts_per_launch": t["valu_insts_per_launch"], "fp64_share": t.get("fp64_share"),
-                                         "model": t.get("model"), "clock_ghz": t.get("clock_ghz"), "source": t.get("source"),
-                                         # same launches inside the counter pass, at the SQ clock measured there
-                                         "profiled_clock_ghz": t.get("profiled_clock_ghz"),
-                                         "frac_at_profiled_clock": t.get("frac_at_profiled_clock")}
-            except Exception:
-                pass
+        t = pick_valu(load_valu_entries(), N_rank, out["dtype"], args.rc, bool(args.mixture))
+        if t is not None and force_avg_s > 0:
+            out["valu_issue"] = {"kernel": t.get("kernel", "lj_force_nbr (fused)"), "floor_ms": t["issue_floor_ms"],
+                                 "avg_launch_ms": force_avg_s * 1e3, "frac": t["issue_floor_ms"] / (force_avg_s * 1e3),
+                                 "valu_insts_per_launch": t["valu_insts_per_launch"], "fp64_share": t.get("fp64_share"),
+                                 "fp32_share": t.get("fp32_share"),
+                                 "model": t.get("model"), "clock_ghz": t.get("clock_ghz"), "source": t.get("source"),
+                                 # same launches inside the counter pass, at the SQ clock measured there
+                                 "profiled_clock_ghz": t.get("profiled_clock_ghz"),
+                                 "frac_at_profiled_clock": t.get("frac_at_profiled_clock"),
+                                 "valu_busy_fraction": t.get("valu_busy_fraction")}
     # ---- the north-star target box (>= 10^8 atoms) on the same ranks: a second, smaller measurement riding on the N > 1
     # runs, so that the driver's 1/2/4/8-GPU sweep also yields the strong-scaling curve of the target size.  `value` above
     # stays the BASELINE metric (the 10^7-atom box); a failure here is reported inside the object and changes nothing else.

@@ -1484,13 +1484,33 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
                 block2(q, b0);
                 return;
             }
+#ifndef EMDEE_PREFETCH_XJ
+#define EMDEE_PREFETCH_XJ 1
+#endif
+            // (EMDEE_PREFETCH_XJ, on: the coordinates of entry t + 1 are requested before the arithmetic of entry t, as in the typed
+            // kernels -- round 5, same-box A/B of the build: fused launch 1.290 -> 1.280 ms, 600 -> 603.6 steps/s; =0 is the A/B baseline)
+            constexpr bool AHEAD = SOA && EMDEE_PREFETCH_XJ != 0;
+            real xn = 0, yn = 0, zn = 0;
+            if (AHEAD) {
+                const unsigned char *pn = plane_b + pick16(q, 0);
+                xn = *reinterpret_cast<const real *>(pn); yn = *reinterpret_cast<const real *>(pn + PLANE_BYTES);
+                zn = *reinterpret_cast<const real *>(pn + 2 * PLANE_BYTES);
+            }
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
                 if (b0 + t * G >= wm) break;                  // wave-uniform; entries past a row's end are sentinels
                 {
                     const int sj = SOA ? pick16(q, t) : (pick16(q, t) >> a.idx_shift);
                     real xj, yj, zj, hs_j, te_j;
-                    if (SOA) {
+                    if (AHEAD) {
+                        xj = xn; yj = yn; zj = zn;
+                        if (t + 1 < EPL) {
+                            const unsigned char *pj = plane_b + pick16(q, t + 1);
+                            xn = *reinterpret_cast<const real *>(pj); yn = *reinterpret_cast<const real *>(pj + PLANE_BYTES);
+                            zn = *reinterpret_cast<const real *>(pj + 2 * PLANE_BYTES);
+                        }
+                        hs_j = te_j = 0;
+                    } else if (SOA) {
                         const unsigned char *pj = plane_b + sj;          // byte offset: three reads off one address register
                         xj = *reinterpret_cast<const real *>(pj);
                         yj = *reinterpret_cast<const real *>(pj + PLANE_BYTES);

@@ -751,8 +751,9 @@ struct NbSystem {
     // the near/far build, rows short enough for the two counts to share cnt[p]
     bool far_skip_active() const {
         const char *on = exp_env("EMDEE_FAR_SKIP");
-        return on != nullptr && std::atoi(on) != 0 && near_far_scale() > 0.0 && brick_active && !typed_active && !has_ghosts && stride < 256 && build_alg == 3 && variant == 0;
+        return on != nullptr && std::atoi(on) != 0 && nearfar_built && brick_active && !typed_active && !has_ghosts && stride < 256;
     }
+    bool nearfar_built = false;           // the list in use was written by the near/far build (ALG 23)
     double near_far_scale() const {
         const char *on = exp_env("EMDEE_BUILD_NEARFAR");
         if (on == nullptr || std::atoi(on) == 0) return 0.0;
@@ -898,6 +899,7 @@ struct NbSystem {
             EMDEE_REQUIRE((double)n * stride < 1.7e10, EMDEE_ERR_OVERFLOW, "neighbour list would exceed 64 GiB");
             if (in_edit && !brick_active) { edit_abort = true; return; }   // (the direct kernels count atoms on the host: the caller reloads)
             bool launched4 = false;
+            nearfar_built = false;
             if (!(kept && attempt == 0)) Zeros().add(flags.ptr, 5).run(stream());   // (a kept plan cleared them with the maxima)
             if (exp_env("EMDEE_FAR_SKIP")) Zeros().add(flags.ptr + 16, 1).run(stream());   // (experiment: the near word starts afresh)
             if (brick_active) {
@@ -981,7 +983,10 @@ struct NbSystem {
                                 }
                             }
                             // ... and near entries first (brick.hpp ALG 23), when the skin leaves room for a near radius
-                            if (build_alg == 3 && strided_ok && near_far_scale() > 0.0) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 23, V::G>;
+                            if (build_alg == 3 && strided_ok && near_far_scale() > 0.0) {
+                                kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 23, V::G>;
+                                nearfar_built = true;
+                            }
 #endif
                             if (build_alg == 5 && strided_ok) kernel = k_brick_build<real, typename V::Shape, V::THREADS, V::GB, 15, V::G>;
                         }

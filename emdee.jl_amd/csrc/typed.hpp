@@ -642,13 +642,24 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
         real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
         // one block of 8 G neighbours of one species: lane gl holds entries b0 + gl + t G, t = 0..7, in q
         auto block = [&](const uint4 &q, int b0, int wm, int m, const PairC &c) {
+            // The coordinates of entry t + 1 are requested BEFORE the arithmetic of entry t (round 5): this kernel runs four
+            // wavefronts per SIMD (one 1024-thread workgroup per CU: the rc = 3.5 sigma tile fills the LDS), too few to hide
+            // the three dependent LDS reads of every pair step behind other waves -- SQ counters: the vector units were busy
+            // 70 % of the kernel against 87 % in the single-species kernel at six waves (profiles/r05/valu_f64_mix_rc3.5.txt).
+            // Every entry of a block is readable whatever the trip count (sentinels pad a segment): the read ahead is safe.
+            const unsigned char *pn = plane_b + pick16(q, 0);
+            real xn = *reinterpret_cast<const real *>(pn), yn = *reinterpret_cast<const real *>(pn + PLANE_BYTES),
+                 zn = *reinterpret_cast<const real *>(pn + 2 * PLANE_BYTES);
 #pragma unroll
             for (int t = 0; t < EPL; t++) {
                 if (b0 + t * G >= wm) break;                  // wave-uniform; entries past a segment's end are sentinels
-                const unsigned char *pj = plane_b + pick16(q, t);        // byte offset: three reads off one address register
-                const real xj = *reinterpret_cast<const real *>(pj);
-                const real yj = *reinterpret_cast<const real *>(pj + PLANE_BYTES);
-                const real zj = *reinterpret_cast<const real *>(pj + 2 * PLANE_BYTES);
+                const real xj = xn, yj = yn, zj = zn;
+                if (t + 1 < EPL) {
+                    const unsigned char *pj = plane_b + pick16(q, t + 1);    // byte offset: three reads off one address register
+                    xn = *reinterpret_cast<const real *>(pj);
+                    yn = *reinterpret_cast<const real *>(pj + PLANE_BYTES);
+                    zn = *reinterpret_cast<const real *>(pj + 2 * PLANE_BYTES);
+                }
                 const real dx = xi - xj, dy = yi - yj, dz = zi - zj;
                 const real r2 = dx * dx + dy * dy + dz * dz;
                 if (MODE == BRICK_STATS) {

@@ -104,12 +104,21 @@ if sq:
         lines.append("inside this counter pass the kernel took %.3f ms at SQ_BUSY_CYCLES / 32 / duration = %.3f GHz: issue floor "
                      "at that clock %.3f ms = %.2f of the measured time" % (prof_ms, clock, floor_clock_ms, floor_clock_ms / prof_ms))
     open(os.path.join(dst, "final_pmc_sq.txt"), "w").write("\n".join(lines) + "\n")
-    json.dump(dict(source="profiles/%s/final_pmc_sq.txt (profiles/collect.sh)" % tag, atoms=N, dtype=bench["dtype"],
-                   valu_insts_per_launch=insts, valu_trans_f64_per_launch=trans, fp64_share=f64 / insts if insts else None,
-                   simds=simds, clock_ghz=clock_ghz, issue_floor_ms=floor_ms, profiled_ms=prof_ms, profiled_clock_ghz=clock,
-                   issue_floor_at_profiled_clock_ms=floor_clock_ms,
-                   frac_at_profiled_clock=floor_clock_ms / prof_ms if clock else None,
-                   model="wave64 VALU instruction = 4 SIMD cycles, TRANS_F64 = 16"),
-              open(os.path.join(root, "valu.json"), "w"), indent=1)
+    ventry = dict(source="profiles/%s/final_pmc_sq.txt (profiles/collect.sh)" % tag, atoms=int(N), dtype=bench["dtype"],
+                  rc=float(bench["config"].get("rc", 2.5)), mixture=bool(bench["config"].get("mixture", False)),
+                  kernel="k_brick<..., BRICK_STEP, 1> (lj_force_nbr with the fused velocity-Verlet update)",
+                  valu_insts_per_launch=insts, valu_trans_per_launch=trans, fp64_share=f64 / insts if insts else None,
+                  simds=simds, clock_ghz=clock_ghz, issue_floor_ms=floor_ms, profiled_ms=prof_ms, profiled_clock_ghz=clock,
+                  issue_floor_at_profiled_clock_ms=floor_clock_ms,
+                  frac_at_profiled_clock=floor_clock_ms / prof_ms if clock else None,
+                  model="wave64 VALU instruction = 4 SIMD cycles, TRANS_F64 = 16")
+    vpath = os.path.join(root, "valu.json")
+    vdata = {"entries": []}
+    if os.path.exists(vpath):
+        vold = json.load(open(vpath))
+        vdata = vold if "entries" in vold else {"entries": [dict(vold, rc=2.5, mixture=False)]}
+    vkey = lambda e: (int(e["atoms"]), e["dtype"], float(e.get("rc", 2.5)), bool(e.get("mixture", False)))
+    vdata["entries"] = sorted([e for e in vdata["entries"] if vkey(e) != vkey(ventry)] + [ventry], key=vkey)
+    json.dump(vdata, open(vpath, "w"), indent=1)
     print("valu issue floor: %.3f ms per launch" % floor_ms)
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "step_roofline", "cpu_baseline") if k in bench})[:1500])

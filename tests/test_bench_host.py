@@ -223,3 +223,29 @@ def test_a_line_only_carries_traffic_measured_on_its_own_configuration():
     # and an entry that claims less than the algorithmic bytes is refused even on its own key
     low = [dict(head, lj_force_nbr_bytes_per_launch=int(0.9 * alg(8, 2.5)))]     # (what round 3 attached to the mixture line was 0.56 of its algorithmic bytes)
     assert bench.pick_traffic(low, N, "f64", 2.5, False, alg(8, 2.5)) is None
+
+
+def test_a_line_only_carries_the_issue_floor_of_its_own_kernel():
+    """VERDICT r4 missing #3: profiles/valu.json is keyed like traffic.json -- (atoms per GPU, dtype, rc, one or two species) --
+    and bench.py attaches `valu_issue` on an exact match only: the instruction count of the single-species fp64 kernel is not
+    offered to the fp32 line or to the mixture's typed kernel (round 4 dropped `valu_issue` for mixtures instead of
+    measuring theirs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    entries = bench.load_valu_entries()
+    assert entries, "profiles/valu.json holds the headline configuration at least"
+    keys = [(int(e["atoms"]), e["dtype"], float(e.get("rc", 2.5)), bool(e.get("mixture", False))) for e in entries]
+    assert len(set(keys)) == len(keys)
+    N = 10061824
+    head = bench.pick_valu(entries, N, "f64", 2.5, False)
+    assert head is not None and 0.5 < head["issue_floor_ms"] < 1.5 and head["valu_insts_per_launch"] > 1e8
+    for atoms, dtype, rc, mix in ((N, "f64", 3.5, True), (N, "f32", 2.5, False), (1000188, "f64", 2.5, False), (N, "f64", 2.5, True)):
+        t = bench.pick_valu(entries, atoms, dtype, rc, mix)
+        if t is not None:
+            assert (int(t["atoms"]), t["dtype"], float(t["rc"]), bool(t["mixture"])) == (atoms, dtype, rc, mix)
+            assert t["issue_floor_ms"] > 0 and ("k_typed" in t["kernel"]) == mix
+    only_head = [dict(head)]
+    assert bench.pick_valu(only_head, N, "f64", 3.5, True) is None and bench.pick_valu(only_head, N, "f32", 2.5, False) is None
+    assert bench.pick_valu([dict(head, issue_floor_ms=None)], N, "f64", 2.5, False) is None

@@ -402,15 +402,16 @@ def test_operator_calls_that_outrun_their_list(emdee, oracle, dev, monkeypatch, 
     for form in ("resort", "reload"):
         if form == "reload":
             monkeypatch.setenv("EMDEE_OPERATOR_RELOAD", "1")
-        mover = np.random.default_rng(5)
         x = x0.copy()
         eps, sigma = make_atoms(3, 1.0)
         tiles = E.nonbonded_computation_tiles(N, skin=skin)
         builds, out = [], []
-        for amp, edit in script:
-            step = mover.uniform(-1, 1, size=x.shape)
-            step /= np.linalg.norm(step, axis=1, keepdims=True)
-            x = x + amp * step
+        for call, (amp, edit) in enumerate(script):
+            # a smooth displacement field (one long wave per call, another direction each time): atoms move past skin / 2
+            # together with their neighbours, so the fluid stays a fluid (random kicks of 0.4 sigma would push pairs to r = 0.6)
+            kv = np.roll(np.array([1.0, 2.0, 0.0]), call) * 2.0 * np.pi / L
+            pol = np.roll(np.array([0.0, 0.6, 0.8]), call)
+            x = x + amp * np.sin(x0 @ kv + 0.7 * call)[:, None] * pol[None, :]
             if edit is not None:
                 eps, sigma = make_atoms(*edit)
             atoms = E.lennard_jones_atoms(eps, sigma)
