@@ -58,6 +58,10 @@ SIGNATURES = {
     "emdee_nbr_destroy": [_p],
     "emdee_nbr_stats": [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32)],
     "emdee_nbr_count_pairs": [_p, C.POINTER(_i64)],
+    "emdee_nbr_set_exclusions": [_p, _p, _i32],
+    "emdee_nbr_set_pairs14": [_p, _p, _i32, _dbl],
+    "emdee_md_set_exclusions": [_p, _p, _i32],
+    "emdee_md_set_pairs14": [_p, _p, _i32, _dbl],
     "emdee_nbr_list": [_p, _p, _p, _i32],
     "emdee_md_nbr_list": [_p, _p, _p, _i32],
     "emdee_compute_nonbonded": [_p, _p, _p, _p, _p, _dbl, _p, LJModelC, _p, _i32, _i32],

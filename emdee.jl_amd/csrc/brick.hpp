@@ -1678,6 +1678,47 @@ __global__ __launch_bounds__(THREADS) void k_brick_export(BrickArgs<real> a, int
     }
 }
 
+// Rows without their excluded entries (kernels.hpp, "exclusions and 1-4 pairs"): run right after a build when the caller
+// named pairs to leave out.  One thread per own atom that has exclusions: its entries are decoded as k_brick_export does
+// (tile slot -> cell-order slot -> caller id), looked up in the atom's sorted exclusion list, and the row is compacted in
+// place, the vacated tail refilled with the sentinel.  Untyped rows only (a box with exclusions keeps the general kernels).
+template <typename real, class Shape, int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void k_brick_filter(BrickArgs<real> a, const int *__restrict__ ex_start,
+                                                          const int *__restrict__ ex_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    BrickTables<Shape, THREADS> T;
+    T.carve(s_dyn);
+    int bxi, byi, bzi, tile_n, n_own;
+    if (!brick_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
+    for (int o = threadIdx.x; o < n_own; o += THREADS) {
+        int ti, p;
+        brick_locate(T, o, ti, p);
+        const int i = a.perm[p];
+        if (i >= a.n_owned) continue;
+        const int lo_x = ex_start[i], hi_x = ex_start[i + 1];
+        if (lo_x == hi_x) continue;
+        const int m = min(a.cnt[p], a.stride);
+        unsigned short *row = a.nbr + (size_t)p * a.stride;
+        int w = 0;
+        for (int e = 0; e < m; e++) {
+            const unsigned short ent = row[row_position<G>((unsigned)e)];
+            const int sl = (int)ent >> a.idx_shift;
+            int lo = 0, hi = Shape::NTC;                  // tile cell with off[tc] <= sl < off[tc + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (T.off[mid] <= sl) lo = mid; else hi = mid;
+            }
+            const int j = a.perm[T.gbeg[lo] + (sl - T.off[lo])];
+            if (!csr_holds(ex_idx, lo_x, hi_x, j)) {
+                if (w != e) row[row_position<G>((unsigned)w)] = ent;
+                w++;
+            }
+        }
+        for (int e = w; e < m; e++) row[row_position<G>((unsigned)e)] = 0;   // the sentinel slot
+        a.cnt[p] = w;
+    }
+}
+
 // Largest tile (brick + halo population) and largest own population over all bricks -> sizes the
 // dynamic LDS of the brick kernels.  out[0] = max tile, out[1] = max own, out[2] = most atoms in three
 // consecutive cells of a tile row (what one group of the build kernel scans per row).

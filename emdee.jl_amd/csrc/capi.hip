@@ -251,6 +251,19 @@ int32_t emdee_md_nbr_list(emdee_md *md, int32_t *counts_dev, int32_t *neighbors_
     return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->export_list(counts_dev, neighbors_dev, capacity); });
 }
 
+int32_t emdee_nbr_set_exclusions(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs) {
+    return guarded([&] { REQUIRE_PTR(nbr, "nbr"); nbr->impl->set_pairs(pairs_dev, n_pairs, false, 1.0); });
+}
+int32_t emdee_nbr_set_pairs14(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale) {
+    return guarded([&] { REQUIRE_PTR(nbr, "nbr"); nbr->impl->set_pairs(pairs_dev, n_pairs, true, lj14scale); });
+}
+int32_t emdee_md_set_exclusions(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->set_pairs(pairs_dev, n_pairs, false, 1.0); });
+}
+int32_t emdee_md_set_pairs14(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale) {
+    return guarded([&] { REQUIRE_PTR(md, "md"); md->impl->set_pairs(pairs_dev, n_pairs, true, lj14scale); });
+}
+
 int32_t emdee_compute_nonbonded(emdee_ctx *ctx, void *forces_dev, void *energies_dev, void *virials_dev,
                                 const void *positions_dev, double L, emdee_nbr *nbr, emdee_lj_model model,
                                 const emdee_lj_atom *atoms_dev, int32_t bitmask, int32_t precision) {

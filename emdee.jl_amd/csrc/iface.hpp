@@ -21,6 +21,7 @@ struct INbr {
     virtual void stats(int64_t *builds, int64_t *listed, int32_t *max_count, int32_t *capacity) = 0;
     virtual void count_pairs(int64_t *pairs) = 0;
     virtual void export_list(int32_t *counts, int32_t *neighbors, int32_t capacity) = 0;
+    virtual void set_pairs(const int32_t *pairs, int32_t n_pairs, bool one_four, double lj14scale) = 0;
 };
 
 struct IMd {
@@ -47,6 +48,7 @@ struct IMd {
     virtual void set_langevin(double gamma, double temperature, uint64_t seed, uint64_t first_step) = 0;
     virtual void set_langevin_ids(const int64_t *ids) = 0;
     virtual void langevin_normals(uint64_t seed, uint64_t step, const int64_t *ids, int n, double *out) = 0;
+    virtual void set_pairs(const int32_t *pairs, int32_t n_pairs, bool one_four, double lj14scale) = 0;
 };
 
 // spatial domain decomposition (emdee_dd_*): the domains of the decomposition that live in this process

@@ -139,6 +139,10 @@ struct NbrImpl : INbr {
         use_device(sys.ctx);
         sys.export_list(counts, neighbors, capacity);
     }
+    void set_pairs(const int32_t *pairs, int32_t n_pairs, bool one_four, double lj14scale) override {
+        use_device(sys.ctx);
+        sys.set_pair_tables(N, one_four ? nullptr : pairs, one_four ? 0 : n_pairs, !one_four, one_four ? pairs : nullptr, one_four ? n_pairs : 0, one_four, lj14scale);
+    }
 };
 
 // ------------------------------------------------------------------------------------ velocity-Verlet
@@ -336,6 +340,16 @@ struct MdImpl : IMd {
         sys.set_langevin(gamma, temperature, seed, first_step, sys.lgv_ids);
     }
     void set_langevin_ids(const int64_t *ids) override { sys.lgv_ids = reinterpret_cast<const long long *>(ids); }
+    void set_pairs(const int32_t *pairs, int32_t n_pairs, bool one_four, double lj14scale) override {
+        use_device(sys.ctx);
+        EMDEE_REQUIRE(sys.sorted && n_ghost == 0 && !sys.id_gaps, EMDEE_ERR_STATE, "exclusions / 1-4 pairs: set them on a loaded integrator without ghosts (call emdee_md_set_state first)");
+        sys.set_pair_tables(sys.n_owned, one_four ? nullptr : pairs, one_four ? 0 : n_pairs, !one_four, one_four ? pairs : nullptr, one_four ? n_pairs : 0, one_four, lj14scale);
+        sys.resort();                                        // the list without the named pairs (a two-species box leaves the typed kernels)
+        since_build = 0;
+        sys.compute_forces(EMDEE_FORCES);
+        current_mask = EMDEE_FORCES;
+        EMDEE_HIP_CHECK(hipGetLastError());
+    }
     void langevin_normals(uint64_t seed, uint64_t step, const int64_t *ids, int n, double *out) override {
         use_device(sys.ctx);
         if (n <= 0) return;

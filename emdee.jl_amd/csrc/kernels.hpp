@@ -999,6 +999,87 @@ static __global__ void k_export_rows(int n, int n_owned, const int *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------ exclusions and 1-4 pairs
+// (the hooks of src/modelling.jl:197-200.  The reference parses lj14scale and nothing consumes it --
+// its hot path sums every pair, src/nonbonded.jl:129-150 -- so these are build-defined: pairs named by the caller are struck
+// from the neighbour rows right after every build (the pair loop gets no mask), and the 1-4 pairs among them are
+// evaluated on their own, scaled.)  Both tables are symmetric CSR lists over caller ids, partners ascending.
+__device__ __forceinline__ bool csr_holds(const int *__restrict__ idx, int lo, int hi, int j) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = idx[mid];
+        if (v == j) return true;
+        if (v < j) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// rows of the direct (int32, cell-order slot) list without their excluded entries
+static __global__ void k_filter_rows(int n, int n_owned, const int *__restrict__ perm, int *__restrict__ nbr, int stride,
+                                     int *__restrict__ cnt, const int *__restrict__ ex_start, const int *__restrict__ ex_idx) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = perm[p];
+    if (i >= n_owned) return;
+    const int lo = ex_start[i], hi = ex_start[i + 1];
+    if (lo == hi) return;
+    int *row = nbr + (size_t)p * stride;
+    const int m = min(cnt[p], stride);
+    int w = 0;
+    for (int e = 0; e < m; e++) {
+        const int q = row[e];
+        if (!csr_holds(ex_idx, lo, hi, perm[q])) row[w++] = q;
+    }
+    cnt[p] = w;
+}
+
+// 1-4 pairs: owner-computes over the symmetric table (no atomics, a fixed order of summation); the scaled pair terms are
+// ADDED to what the list kernels have left -- in the cell-ordered arrays, or in the caller's arrays when the operator
+// path had its results written there (user_*: caller order).
+template <typename real>
+__global__ void k_pairs14(int n, int n_owned, size_t pitch, AtomView<real> atoms, const int *__restrict__ perm,
+                          const int *__restrict__ inv_perm, GridP<real> g, LJModel<real> model, const int *__restrict__ start14,
+                          const int *__restrict__ idx14, real scale, int bitmask, real *__restrict__ frc, real *__restrict__ en,
+                          real *__restrict__ vir, real *__restrict__ user_f, real *__restrict__ user_e, real *__restrict__ user_w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = perm[p];
+    if (i >= n_owned) return;
+    const int lo = start14[i], hi = start14[i + 1];
+    if (lo == hi) return;
+    real xi, yi, zi, hs_i, te_i;
+    load_atom(atoms, p, xi, yi, zi, hs_i, te_i);
+    real fx = 0, fy = 0, fz = 0, e = 0, w = 0;
+    for (int k = lo; k < hi; k++) {
+        const int q = inv_perm[idx14[k]];
+        real xj, yj, zj, hs_j, te_j;
+        load_atom(atoms, q, xj, yj, zj, hs_j, te_j);
+        const real dx = min_image(xi - xj, g.plen[0], g.pinv[0]);
+        const real dy = min_image(yi - yj, g.plen[1], g.pinv[1]);
+        const real dz = min_image(zi - zj, g.plen[2], g.pinv[2]);
+        const real r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 < model.rc2) {                                  // CUTOFF semantics, as the list kernels
+            const real inv_r2 = (real)1 / r2;
+            real E, W;
+            lj_interaction(r2, inv_r2, model, hs_i, te_i, hs_j, te_j, E, W);
+            const real wr2 = W * inv_r2;                      // src/nonbonded.jl:139
+            fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
+            e += E; w += W;
+        }
+    }
+    fx *= scale; fy *= scale; fz *= scale;
+    e *= (real)0.5 * scale; w *= (real)0.5 * scale;           // src/nonbonded.jl:142-145: half of a pair's E and W to either atom
+    if (user_f != nullptr || user_e != nullptr || user_w != nullptr) {
+        if ((bitmask & EMDEE_FORCES) && user_f) { user_f[3 * (size_t)i] += fx; user_f[3 * (size_t)i + 1] += fy; user_f[3 * (size_t)i + 2] += fz; }
+        if ((bitmask & EMDEE_ENERGIES) && user_e) user_e[i] += e;
+        if ((bitmask & EMDEE_VIRIALS) && user_w) user_w[i] += w;
+    } else {
+        if (bitmask & EMDEE_FORCES) { frc[p] += fx; frc[pitch + p] += fy; frc[2 * pitch + p] += fz; }
+        if (bitmask & EMDEE_ENERGIES) en[p] += e;
+        if (bitmask & EMDEE_VIRIALS) vir[p] += w;
+    }
+}
+
 // ------------------------------------------------------------------------------------ reductions
 // Deterministic two-stage sums in fp64 (mixed precision: fp32 per-atom values, fp64 totals).
 constexpr int RED_BLOCK = 256;

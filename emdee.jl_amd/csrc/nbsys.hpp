@@ -801,7 +801,7 @@ struct NbSystem {
         // two species: the typed kernels (typed.hpp), if the tile fits their coordinate planes, no three cells of a tile row hold
         // more atoms of one species than the 16-bit hit fields of their build take, and both kernels fit LDS
         typed_active = false;
-        if (brick_active && nt == 2 && !typed_blocked) {
+        if (brick_active && nt == 2 && !typed_blocked && !has_excl) {
             // (where the general-species kernels take 1024 threads with 8 lanes per atom -- long cutoffs -- the typed ones take
             // 1024 threads with 4: rows are two block-aligned segments, and blocks of 32 entries pad them half as much as blocks of 64)
             // Measured (profiles/README.md, round 3): at rc = 3.5 sigma 190.7 -> 218.0 steps/s in fp64 and 233.8 -> 324.2 in fp32; at
@@ -1050,6 +1050,7 @@ struct NbSystem {
             if (needed <= stride) {
                 builds++;
                 has_list = true;
+                apply_exclusions();
                 return;
             }
             stride = (needed + needed / 8 + 15) / 16 * 16;   // grow and rebuild
@@ -1066,6 +1067,90 @@ struct NbSystem {
             if (brick_active && !build_fits_lds()) { brick_active = false; idx_shift = 0; btab_valid = false; plan_valid = false; }
         }
         EMDEE_REQUIRE(false, EMDEE_ERR_OVERFLOW, "neighbour capacity kept overflowing");
+    }
+
+    // ---------------------------------------------------------------- exclusions and 1-4 pairs (kernels.hpp)
+    // Pairs the caller names (caller ids; bonded neighbours of a molecular model) are struck from the rows right after every
+    // build; the 1-4 pairs among them come back scaled (lj14scale of the reference's force-field file, src/modelling.jl:198)
+    // through k_pairs14 after every force pass.  Symmetric CSR tables over caller ids, built on the host once per call
+    // (topology does not change during a run).  Undivided engines only; two-species boxes with exclusions keep the
+    // general-species kernels (a typed row is two block-aligned segments: compacting one would move the other).
+    DevBuf<int> ex_start, ex_idx, p14_start, p14_idx;
+    bool has_excl = false, has_14 = false;
+    double scale14 = 1.0;
+    int table_atoms = 0;
+    std::vector<int32_t> excl_host, p14_host;          // the caller's pairs as given: {i, j, i, j, ...}
+    std::vector<int32_t> fetch_pairs(const int32_t *pairs_dev, int n_pairs) {
+        std::vector<int32_t> h((size_t)2 * n_pairs);
+        if (n_pairs > 0) {
+            EMDEE_HIP_CHECK(hipMemcpyAsync(h.data(), pairs_dev, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+            EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+        }
+        return h;
+    }
+    // pairs {i, j} of caller ids -> symmetric, sorted, duplicate-free CSR (start[n_atoms + 1], idx) on the device
+    void upload_csr(const std::vector<int32_t> &h, int n_atoms, DevBuf<int> &start_out, DevBuf<int> &idx_out) {
+        const size_t np = h.size() / 2;
+        std::vector<std::pair<int32_t, int32_t>> both;
+        both.reserve(2 * np);
+        for (size_t k = 0; k < np; k++) {
+            const int32_t i = h[2 * k], j = h[2 * k + 1];
+            EMDEE_REQUIRE(i >= 0 && j >= 0 && i < n_atoms && j < n_atoms && i != j, EMDEE_ERR_INVALID,
+                          "pair table: pair %zu = (%d, %d) is not a pair of two different atoms of %d", k, i, j, n_atoms);
+            both.emplace_back(i, j);
+            both.emplace_back(j, i);
+        }
+        std::sort(both.begin(), both.end());
+        both.erase(std::unique(both.begin(), both.end()), both.end());
+        std::vector<int32_t> st((size_t)n_atoms + 1, 0), ix(both.size());
+        for (size_t k = 0; k < both.size(); k++) { st[(size_t)both[k].first + 1]++; ix[k] = both[k].second; }
+        for (int a = 0; a < n_atoms; a++) st[(size_t)a + 1] += st[a];
+        start_out.ensure(st.size() + 1); idx_out.ensure(ix.size() + 1);
+        EMDEE_HIP_CHECK(hipMemcpyAsync(start_out.ptr, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream()));
+        if (!ix.empty()) EMDEE_HIP_CHECK(hipMemcpyAsync(idx_out.ptr, ix.data(), ix.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream()));
+        EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+    // set_excl / set_14: which of the two tables this call replaces (n = 0 clears it); scale: lj14scale
+    void set_pair_tables(int n_atoms, const int32_t *excl_dev, int n_excl, bool set_excl, const int32_t *p14_dev, int n_14, bool set_14, double scale) {
+        EMDEE_REQUIRE(n_atoms >= 0 && n_excl >= 0 && n_14 >= 0, EMDEE_ERR_INVALID, "pair table: negative count");
+        EMDEE_REQUIRE((n_excl == 0 || excl_dev) && (n_14 == 0 || p14_dev), EMDEE_ERR_INVALID, "pair table: NULL array");
+        EMDEE_REQUIRE(!set_14 || std::isfinite(scale), EMDEE_ERR_INVALID, "pair table: lj14scale must be finite");
+        if (set_excl) excl_host = fetch_pairs(excl_dev, n_excl);
+        if (set_14) { p14_host = fetch_pairs(p14_dev, n_14); scale14 = scale; }
+        upload_csr(p14_host, n_atoms, p14_start, p14_idx);
+        has_14 = !p14_host.empty();
+        std::vector<int32_t> all = excl_host;                // what is struck from the rows: the exclusions and the 1-4 pairs together
+        all.insert(all.end(), p14_host.begin(), p14_host.end());
+        upload_csr(all, n_atoms, ex_start, ex_idx);
+        has_excl = !all.empty();
+        table_atoms = n_atoms;
+        has_list = false; plan_valid = false;                // (the rows in use were filtered with the old tables; typed rows are not filtered)
+    }
+    // right after a build: the rows without their excluded entries
+    void apply_exclusions() {
+        if (!has_excl || n_total == 0) return;
+        EMDEE_REQUIRE(table_atoms == n_owned && !id_gaps, EMDEE_ERR_STATE, "exclusion tables were set for %d atoms, the state holds %d", table_atoms, n_owned);
+        if (brick_active) {
+            EMDEE_REQUIRE(!typed_active, EMDEE_ERR_STATE, "exclusions: typed rows are not filtered");
+            with_brick_variant(variant, [&](auto v) {
+                using V = decltype(v);
+                auto kernel = k_brick_filter<real, typename V::Shape, V::THREADS, V::G>;
+                using BT = BrickTables<typename V::Shape, V::THREADS>;
+                hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), BT::bytes(0), stream(), brick_args(), ex_start.ptr, ex_idx.ptr);
+            });
+        } else {
+            hipLaunchKernelGGL(k_filter_rows, dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned, perm.ptr, nbr.ptr, stride,
+                               cnt.ptr, ex_start.ptr, ex_idx.ptr);
+        }
+    }
+    // after a force pass: the scaled 1-4 terms on top
+    void add_pairs14(int bitmask) {
+        if (!has_14 || n_total == 0) return;
+        EMDEE_REQUIRE(table_atoms == n_owned && !id_gaps, EMDEE_ERR_STATE, "1-4 table was set for %d atoms, the state holds %d", table_atoms, n_owned);
+        const bool user = brick_active && (out_f || out_e || out_w);
+        hipLaunchKernelGGL((k_pairs14<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_total, n_owned, pitch, view(), perm.ptr,
+                           inv_perm.ptr, grid, model, p14_start.ptr, p14_idx.ptr, (real)scale14, bitmask, frc.ptr, en.ptr, vir.ptr,
+                           user ? out_f : (real *)nullptr, user ? out_e : (real *)nullptr, user ? out_w : (real *)nullptr);
     }
 
     // ---------------------------------------------------------------- forces
@@ -1188,6 +1273,7 @@ struct NbSystem {
                     bool carry_ghosts = true, bool noise_ready = false) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         if (!brick_active || n_total == 0) return false;
+        if (has_14) return false;                            // (the scaled 1-4 terms are added behind a force pass: the split kernels)
         if (phase != 2 && !noise_ready) prepare_noise(dt);   // phases 1 and 2 are the two halves of one step
         {
             Timed t(this, phase == 2 ? T_STEP_BOUNDARY : T_STEP);
@@ -1220,7 +1306,7 @@ struct NbSystem {
     int fused_steps_run_ahead(double c, double dt, int want, bool *stale) {
         EMDEE_REQUIRE(has_list && sorted && with_vel, EMDEE_ERR_STATE, "no state loaded");
         *stale = false;
-        if (!brick_active || n_total == 0 || has_ghosts) return 0;
+        if (!brick_active || n_total == 0 || has_ghosts || has_14) return 0;
         const int B = std::max(1, std::min(want, run_ahead));
         int *words = flags.ptr + 9;                          // flags[9 .. 9 + RUN_AHEAD)
         EMDEE_HIP_CHECK(hipMemsetAsync(words, 0, B * sizeof(int), stream()));
@@ -1261,6 +1347,7 @@ struct NbSystem {
         force_phase = brick_active ? phase : 0;
         if (brick_active) {
             with_brick_variant(variant, [&](auto v) { launch_brick_force<decltype(v)>(bitmask); });
+            add_pairs14(bitmask);
             return;
         }
         switch (bitmask) {
@@ -1272,6 +1359,7 @@ struct NbSystem {
             case 6: launch_direct_force<6>(); break;
             default: launch_direct_force<7>(); break;
         }
+        add_pairs14(bitmask);
     }
 
     // ---------------------------------------------------------------- integrator

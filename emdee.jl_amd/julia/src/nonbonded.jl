@@ -47,6 +47,17 @@ function handle!(tiles::NeighborTiles, precision::Int32)
     return tiles.handle
 end
 
+# int32_t emdee_nbr_set_exclusions(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs);
+# int32_t emdee_nbr_set_pairs14(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale);
+# Exclusions and scaled 1-4 pairs of a molecular model (build-defined: the reference parses lj14scale, src/modelling.jl:197-200,
+# and its hot path never uses it): 2 x n device matrices of 0-based atom indices.  The handle must exist (handle!(tiles, precision)).
+set_exclusions!(tiles::NeighborTiles, pairs::Union{Nothing,HipArray{Int32,2}}; precision::Int32=Int32(8)) =
+    check(ccall((:emdee_nbr_set_exclusions, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), handle!(tiles, precision),
+                pairs === nothing ? C_NULL : pairs.ptr, pairs === nothing ? 0 : size(pairs, 2)))
+set_pairs14!(tiles::NeighborTiles, pairs::Union{Nothing,HipArray{Int32,2}}, lj14scale; precision::Int32=Int32(8)) =
+    check(ccall((:emdee_nbr_set_pairs14, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), handle!(tiles, precision),
+                pairs === nothing ? C_NULL : pairs.ptr, pairs === nothing ? 0 : size(pairs, 2), Float64(lj14scale)))
+
 # compute_nonbonded!(forces, energies, virials, positions, L, tiles, model, atoms, Val(bitmask))
 # -- src/nonbonded.jl:109-120.  positions/forces are 3xN device matrices, energies/virials length N,
 # atoms a device vector of LJAtom.  Selected outputs are overwritten; asynchronous like the reference.

@@ -37,6 +37,17 @@ set_langevin!(md::VelocityVerlet, gamma, temperature; seed=0, first_step=0) =
     check(ccall((:emdee_md_set_langevin, libemdee_hip), Int32, (Ptr{Cvoid}, Float64, Float64, UInt64, UInt64),
                 md.handle, gamma, temperature, seed, first_step))
 
+# int32_t emdee_md_set_exclusions(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs);
+# int32_t emdee_md_set_pairs14(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale);
+# pairs: 2 x n device matrix of 0-based atom indices (the hooks of src/modelling.jl:197-200: bonded neighbours contribute
+# nothing, 1-4 pairs lj14scale times their pair terms); after the state is loaded; `nothing` clears the table.
+set_exclusions!(md::VelocityVerlet, pairs::Union{Nothing,HipArray{Int32,2}}) =
+    check(ccall((:emdee_md_set_exclusions, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), md.handle,
+                pairs === nothing ? C_NULL : pairs.ptr, pairs === nothing ? 0 : size(pairs, 2)))
+set_pairs14!(md::VelocityVerlet, pairs::Union{Nothing,HipArray{Int32,2}}, lj14scale) =
+    check(ccall((:emdee_md_set_pairs14, libemdee_hip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), md.handle,
+                pairs === nothing ? C_NULL : pairs.ptr, pairs === nothing ? 0 : size(pairs, 2), Float64(lj14scale)))
+
 # int32_t emdee_md_set_langevin_ids(emdee_md *md, const int64_t *ids_dev);
 # Atom ids keying the thermostat's noise (device Int64 vector in caller order); `nothing` = the caller index.
 set_langevin_ids!(md::VelocityVerlet, ids::Union{Nothing,HipArray{Int64,1}}) =

@@ -49,6 +49,7 @@ class NeighborTiles:
         self._handle = None
         self._key = None
         self._ctx = None
+        self._excl, self._p14, self._scale14 = None, None, 1.0
 
     def __len__(self):
         n = -(-self.N // WAVESIZE)
@@ -62,7 +63,42 @@ class NeighborTiles:
             h = C.c_void_p()
             _lib.call("emdee_nbr_create", ctx.handle, self.N, self.skin, precision, C.byref(h))
             self._handle, self._key, self._ctx = h, key, ctx
+            self._apply_pairs()
         return self._handle
+
+    # -- exclusions and 1-4 pairs (include/emdee_hip.h: emdee_nbr_set_exclusions / emdee_nbr_set_pairs14; the hooks of the
+    # reference's force-field file, src/modelling.jl:197-200, which its own hot path never consumes)
+    @staticmethod
+    def _pairs(pairs):
+        if pairs is None:
+            return None
+        t = torch.as_tensor(pairs)
+        if t.numel() == 0:
+            return None
+        if t.dim() != 2 or t.shape[1] != 2:
+            raise ValueError("pairs: an (n, 2) array of atom indices")
+        return t.to(dtype=torch.int32).contiguous()
+
+    def _apply_pairs(self):
+        if self._handle is None:
+            return
+        dev = self._ctx.device
+        for name, t, extra in (("emdee_nbr_set_exclusions", self._excl, ()), ("emdee_nbr_set_pairs14", self._p14, (float(self._scale14),))):
+            if t is None:
+                _lib.call(name, self._handle, None, 0, *extra)
+            else:
+                td = t.to(dev)
+                _lib.call(name, self._handle, C.c_void_p(td.data_ptr()), int(td.shape[0]), *extra)
+
+    def set_exclusions_(self, pairs):
+        """pairs (n, 2) of atom indices that contribute nothing (bonded neighbours); None / empty clears the table."""
+        self._excl = self._pairs(pairs)
+        self._apply_pairs()
+
+    def set_pairs14_(self, pairs, lj14scale):
+        """pairs (n, 2) whose pair terms count lj14scale times (NonbondedTable.lj14scale of a force-field file); None clears."""
+        self._p14, self._scale14 = self._pairs(pairs), float(lj14scale)
+        self._apply_pairs()
 
     def stats(self):
         """dict(builds, listed, max_count, capacity) of the current list (blocking)."""

@@ -180,6 +180,15 @@ class VelocityVerlet:
                   C.c_void_p(ids.data_ptr()), int(ids.shape[0]), C.c_void_p(out.data_ptr()))
         return out
 
+    # -- exclusions and 1-4 pairs (include/emdee_hip.h; set after the state is loaded, undivided boxes)
+    def set_exclusions_(self, pairs):
+        t = torch.as_tensor(pairs if pairs is not None else []).reshape(-1, 2).to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.call("emdee_md_set_exclusions", self._handle, C.c_void_p(t.data_ptr()) if t.numel() else None, int(t.shape[0]))
+
+    def set_pairs14_(self, pairs, lj14scale):
+        t = torch.as_tensor(pairs if pairs is not None else []).reshape(-1, 2).to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.call("emdee_md_set_pairs14", self._handle, C.c_void_p(t.data_ptr()) if t.numel() else None, int(t.shape[0]), float(lj14scale))
+
     def close(self):
         if self._handle is not None:
             _lib.call("emdee_md_destroy", self._handle)

@@ -144,6 +144,20 @@ int32_t emdee_nbr_count_pairs(emdee_nbr *nbr, int64_t *pairs_in_cutoff);
 int32_t emdee_nbr_list(emdee_nbr *nbr, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity);
 int32_t emdee_md_nbr_list(emdee_md *md, int32_t *counts_dev, int32_t *neighbors_dev, int32_t capacity);
 
+/* Exclusions and 1-4 pairs (build-defined; SURVEY.md 8(f) item 2 "hooks": the reference parses lj14scale from its force-field
+ * file, src/modelling.jl:197-200, and nothing consumes it -- its hot path sums every pair, src/nonbonded.jl:129-150).
+ * pairs_dev: n_pairs pairs {i, j} of atom indices (caller order, 2 n_pairs int32, device); copied.  A pair named by
+ * emdee_*_set_exclusions contributes nothing; a pair named by emdee_*_set_pairs14 contributes lj14scale times its pair terms
+ * (forces, energy and virial halves).  Both are struck from the neighbour rows right after every list build -- the pair loop
+ * carries no mask -- and the 1-4 pairs are evaluated by a kernel of their own behind every force pass (an integrator with
+ * 1-4 pairs steps with the split kernels: force pass, 1-4 terms, kick + drift).  Each call replaces its table; n_pairs = 0
+ * clears it.  Undivided boxes (emdee_nbr, emdee_md without ghosts); emdee_md: after emdee_md_set_state.  Two-species boxes with
+ * exclusions keep the general-species kernels. */
+int32_t emdee_nbr_set_exclusions(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs);
+int32_t emdee_nbr_set_pairs14(emdee_nbr *nbr, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale);
+int32_t emdee_md_set_exclusions(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs);
+int32_t emdee_md_set_pairs14(emdee_md *md, const int32_t *pairs_dev, int32_t n_pairs, double lj14scale);
+
 /* compute_nonbonded!(forces, energies, virials, positions, L, tiles, model, atoms, Val(bitmask))
  * -- src/nonbonded.jl:109-120 -- O(N) neighbour-list path, EMDEE_CUTOFF semantics.
  * Outputs not selected by bitmask may be NULL and are left untouched; selected outputs are

@@ -445,3 +445,102 @@ def test_operator_calls_that_outrun_their_list(emdee, oracle, dev, monkeypatch, 
 def builds_changed(builds, k):
     return k == 0 or builds[k] != builds[k - 1]
 
+
+
+def _pair_terms(oracle, x, L, om, atoms, pairs):
+    """(f, e, w) contributions of the named pairs alone: the oracle's pair function (oracle.interaction = interaction() of
+    src/lennard_jones.jl:25-42, CUTOFF mode) at the minimum-image distance (src/nonbonded.jl:40), f = W / r^2 r_ij and half
+    of E and W to either atom (src/nonbonded.jl:136-145)."""
+    f, e, w = np.zeros_like(x), np.zeros(x.shape[0]), np.zeros(x.shape[0])
+    for i, j in pairs:
+        d = x[i] - x[j]
+        d -= L * np.rint(d / L)
+        r2 = float(d @ d)
+        E, W = oracle.interaction(r2, om, atoms[i], atoms[j], mode=oracle.CUTOFF)
+        f[i] += W / r2 * d; f[j] -= W / r2 * d
+        e[i] += 0.5 * E; e[j] += 0.5 * E
+        w[i] += 0.5 * W; w[j] += 0.5 * W
+    return f, e, w
+
+
+@pytest.mark.parametrize("path", ["tiled", "direct"])
+def test_exclusions_and_scaled_14_pairs(emdee, oracle, dev, lj_sample, monkeypatch, path):
+    """SURVEY.md 8(f) item 2, the hooks of src/modelling.jl:197-200 (lj14scale is parsed by the reference and consumed by
+    nothing): a molecular-like box cut out of the reference's own fixture -- consecutive atoms of lj_sample.xyz chained into
+    4-atom "molecules" (1-2 and 1-3 neighbours excluded, 1-4 pairs scaled by the lj14scale of the reference's force-field
+    fixture) -- through compute_nonbonded_ and through the integrator, against the oracle's sum over ALL pairs minus the
+    excluded pairs' terms plus the scaled 1-4 terms.  A 4,000-atom periodic copy takes the tiled kernels (rows filtered after
+    the build, the pair loop has no mask), EMDEE_PATH=direct the global-gather ones."""
+    E = emdee
+    if path == "direct":
+        monkeypatch.setenv("EMDEE_PATH", "direct")
+    table = E.ingest.NonbondedTable(os.path.join(GOLDEN, "dibenzo-p-dioxin-in-water.xml"))
+    s14 = table.lj14scale
+    assert 0.0 < s14 < 1.0
+    # 5 periodic images of the 800-atom fixture side by side along x: a box of 50 x 10 x 10 would break cubic periodicity, so
+    # instead the fixture itself (L = 10, rc = 3: tiled kernels need L >= 2 (rc + skin), i.e. three cells: 10 / 3.3) is used as is
+    x = lj_sample.astype(np.float64)
+    N, L = x.shape[0], 10.0
+    rc, rs = 3.0, 2.5
+    kind = np.arange(N) % 4
+    eps = np.array([1.0, 0.8, 1.1, 0.9])[kind]
+    sigma = np.array([1.0, 0.9, 1.05, 0.95])[kind]
+    atoms = E.lennard_jones_atoms(eps, sigma)
+    mol = np.arange(N).reshape(-1, 4)
+    excl = np.concatenate([mol[:, [0, 1]], mol[:, [1, 2]], mol[:, [2, 3]], mol[:, [0, 2]], mol[:, [1, 3]]])
+    p14 = mol[:, [0, 3]]
+    om = oracle.model(rc, rs)
+    f0, e0, w0 = oracle.nonbonded_cells(x, L, om, atoms)
+    fx, ex, wx = _pair_terms(oracle, x, L, om, atoms, excl)
+    f4, e4, w4 = _pair_terms(oracle, x, L, om, atoms, p14)
+    want = (f0 - fx - (1.0 - s14) * f4, e0 - ex - (1.0 - s14) * e4, w0 - wx - (1.0 - s14) * w4)
+    assert np.abs(fx).max() > 1e-3 * np.abs(f0).max()                     # the named pairs are inside the cutoff: they matter
+
+    tiles = E.nonbonded_computation_tiles(N, skin=0.3)
+    tiles.set_exclusions_(excl)
+    tiles.set_pairs14_(p14, s14)
+    f, e, w = (torch.zeros(s, dtype=torch.float64, device=dev) for s in ((N, 3), (N,), (N,)))
+    E.compute_nonbonded_(f, e, w, E.cu(x, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(7))
+    for got, ref in zip((f, e, w), want):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    # the rows no longer hold the named pairs (either direction), and nothing else went missing
+    rows = _rows(*tiles.neighbor_lists())
+    full = _oracle_rows(oracle, x, L, rc + 0.3)
+    named = {(int(a), int(b)) for a, b in np.concatenate([excl, p14])} | {(int(b), int(a)) for a, b in np.concatenate([excl, p14])}
+    for i in range(N):
+        assert np.array_equal(rows[i], np.array([j for j in full[i] if (i, int(j)) not in named], dtype=rows[i].dtype)), i
+    # a second call after a move past skin / 2 (the re-sort filters again), and clearing the tables gives the plain sum back
+    x2 = x + 0.25 * np.sin(x[:, [1, 2, 0]])
+    E.compute_nonbonded_(f, e, w, E.cu(x2, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(7))
+    g0 = oracle.nonbonded_cells(x2, L, om, atoms)
+    gx, g4 = _pair_terms(oracle, x2, L, om, atoms, excl), _pair_terms(oracle, x2, L, om, atoms, p14)
+    for got, a, b, c in zip((f, e, w), g0, gx, g4):
+        ref = a - b - (1.0 - s14) * c
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    tiles.set_exclusions_(None)
+    tiles.set_pairs14_(None, 1.0)
+    E.compute_nonbonded_(f, e, w, E.cu(x2, dev), L, tiles, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), E.Val(7))
+    assert np.abs(f.cpu().numpy() - g0[0]).max() <= 1e-9 * np.abs(g0[0]).max()
+
+    # the integrator: 1-4 pairs make it step with the split kernels; 20 steps against the oracle's trajectory of the same
+    # modified potential are out of the oracle's reach (it has no exclusions), so: forces at the start, and energy conservation
+    v0 = 0.3 * E.synthetic.velocities(N)
+    md = E.VelocityVerlet(E.cu(x, dev), E.cu(v0, dev), L, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), skin=0.3)
+    md.set_exclusions_(excl)
+    md.set_pairs14_(p14, s14)
+    st = md.state(energies=True, virials=True)
+    assert np.abs(st["forces"].cpu().numpy() - want[0]).max() <= 1e-6 * np.abs(want[0]).max()
+    assert np.abs(st["energies"].cpu().numpy() - want[1]).max() <= 1e-6 * np.abs(want[1]).max()
+    ep0, ek0, _ = md.totals()
+    md.step_(80, 0.001)
+    ep1, ek1, _ = md.totals()
+    assert md.nbr_stats()["builds"] >= 2
+    # (the fixture is not an equilibrium of the modified potential: excluded neighbours fall into each other and the box
+    # heats up several-fold in these steps -- what must hold is the total, to the integrator's dt^2)
+    assert abs((ep1 + ek1) - (ep0 + ek0)) <= 2e-5 * abs(ep0), ((ep0, ek0), (ep1, ek1))
+    half = E.VelocityVerlet(E.cu(x, dev), E.cu(v0, dev), L, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), skin=0.3)
+    half.set_exclusions_(excl)
+    half.set_pairs14_(p14, s14)
+    half.step_(40, 0.002)
+    eph, ekh, _ = half.totals()
+    assert abs((eph + ekh) - (ep0 + ek0)) > 2.5 * abs((ep1 + ek1) - (ep0 + ek0))          # ... and it shrinks with dt^2
