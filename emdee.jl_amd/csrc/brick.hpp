@@ -159,12 +159,39 @@ struct BrickArgs {
     // cnt[p] = total | near << 8, and while NO atom has moved delta / 2 since the build (*far_word == 0: raised like the
     // rebuild trigger, by the launch that produced the positions, read by the next one) a row ends at its near entries -- an
     // entry beyond r_c + delta at the build cannot be inside r_c before two atoms have moved delta / 2 each: the same sums
+    // cell-relative records (kernels.hpp RelGrid; fp32 integrators): a record is relative to the origin of its cell, and a tile
+    // coordinate is record + (tile cell - brick origin) cell widths -- no image shift, no box-sized number anywhere
+    int rel;
+    double rcw[3], rlo[3];
     int far_skip;
     int *far_word;
     real thr2_near;
     const real *user_pos;      // ... read from the CALLER's array (3 x N, caller order): the engine's records hold positions wrapped
                                // into the box, and x - L rounded to fp32 is not the number the reference divides by L
 };
+
+// ---- cell-relative records: tile coordinates (kernels.hpp RelGrid) ---------------------------------
+// the integer (as a float: < 2^24) that takes round(record x 2^19) of an atom of the tile cell at offset t (-1 .. B) from the
+// brick's first own cell b, along dimension d, to its brick-relative tile coordinate in grid points
+template <typename real>
+__device__ __forceinline__ float rel_cell_const(const BrickArgs<real> &a, int d, int b, int t) {
+    const int M = a.g.M[d];
+    int cg = b + t, img = 0;                                 // the cell of the box this tile cell is an image of
+    if (cg < 0) { cg += M; img = -1; } else if (cg >= M) { cg -= M; img = 1; }
+    auto oq = [&](int c) { return rint((a.rlo[d] + (double)c * a.rcw[d]) * 524288.0); };
+    return (float)(oq(cg) + (double)img * oq(M) - (double)img * oq(0) - oq(b));
+}
+// ... for the TX + TY + TZ tile-cell offsets of a brick, into LDS (56 bytes): call with every thread, then a barrier
+template <typename real, class Shape>
+__device__ __forceinline__ void rel_fill_consts(const BrickArgs<real> &a, int bxi, int byi, int bzi, float *relc) {
+    constexpr int TX = Shape::TX, TY = Shape::TY, TZ = Shape::TZ;
+    const int t = threadIdx.x;
+    if (t < TX) relc[t] = rel_cell_const(a, 0, bxi * Shape::BX, t - 1);
+    else if (t < TX + TY) relc[t] = rel_cell_const(a, 1, byi * Shape::BY, t - TX - 1);
+    else if (t < TX + TY + TZ) relc[t] = rel_cell_const(a, 2, bzi * Shape::BZ, t - TX - TY - 1);
+}
+__device__ __forceinline__ float rel_tile(float v, float c) { return (rintf(v * REL_FX) + c) * REL_IFX; }
+__device__ __forceinline__ double rel_tile(double v, float) { return v; }   // (fp64 states are never cell-relative)
 
 // ---- LDS tables shared by the build and force kernels ------------------------------------------
 template <class Shape, int THREADS>
@@ -529,6 +556,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
         org[1] = a.g.lo[1] + (real)(byi * BY) * (a.g.len[1] / (real)a.g.M[1]);
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
+    __shared__ float s_relc[sizeof(real) == 4 ? Shape::TX + Shape::TY + Shape::TZ : 1];   // cell-relative records: rel_cell_const per tile-cell offset
+    if (sizeof(real) == 4 && a.rel) {
+        rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
+        __syncthreads();
+    }
     // own-atom table entries first (their global loads fly while the tile is being staged)
     int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS], own_oc[OWN_REGS];
 #pragma unroll
@@ -550,6 +582,10 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             q.x = (float)(((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]) * ks);
             q.y = (float)(((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]) * ks);
             q.z = (float)(((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]) * ks);
+        } else if (sizeof(real) == 4 && a.rel) {              // cell-relative records: the tile coordinates the force kernels see, to the bit
+            q.x = (float)rel_tile(r.x, s_relc[tc % TX]);
+            q.y = (float)rel_tile(r.y, s_relc[TX + (tc / TX) % TY]);
+            q.z = (float)rel_tile(r.z, s_relc[TX + TY + tc / (TX * TY)]);
         } else {
             q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
             q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
@@ -1326,6 +1362,12 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
     // the 10^7-atom box, and the reason the O(N) path used to miss the reference's own fp32 bound (test/runtests.jl:39-41).
     constexpr bool REL = sizeof(real) == 4;
     const bool refmath = REL && MODE == BRICK_FORCE && !SOA && a.refmath != 0;
+    // cell-relative records: one integer per tile cell and dimension (rel_cell_const), worked out once per workgroup
+    __shared__ float s_relc[REL ? Shape::TX + Shape::TY + Shape::TZ : 1];
+    if (REL && a.rel) {
+        rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
+        __syncthreads();
+    }
     double org[3] = {0.0, 0.0, 0.0};
     if (REL) {
         org[0] = (double)a.g.lo[0] + (double)(bxi * Shape::BX) * ((double)a.g.len[0] / (double)a.g.M[0]);
@@ -1339,6 +1381,9 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         if (refmath) {           // scaled positions, as the reference keeps them (src/nonbonded.jl:52-61,124)
             const size_t i = (size_t)a.perm[gp];
             r.x = a.user_pos[3 * i] / a.g.len[0]; r.y = a.user_pos[3 * i + 1] / a.g.len[1]; r.z = a.user_pos[3 * i + 2] / a.g.len[2];
+        } else if (REL && a.rel) {                            // cell-relative records (BrickArgs::rel): fixed-point tile coordinates
+            r.x = (real)rel_tile(r.x, s_relc[tc % Shape::TX]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + (tc / Shape::TX) % Shape::TY]);
+            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + tc / (Shape::TX * Shape::TY)]);
         } else if (REL) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);

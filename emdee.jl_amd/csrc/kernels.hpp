@@ -36,11 +36,33 @@ struct alignas(16) Rec<float> {
     float x, y, z, hs;
 };
 
+// Cell-relative records (round 5; fp32 integrators): a record holds the atom's position RELATIVE TO THE ORIGIN OF ITS CELL
+// as of the last sort, so that the drift x += dt v of a step rounds at the ulp of a cell-sized number (2.4e-7 sigma) and
+// not at the ulp of the box (1.5e-5 sigma at 10^7 atoms, 3.1e-5 at 10^8 -- against ~5e-3 sigma moved per step: the noise
+// that random-walked the fp32 runs' energy).  Between sorts an atom may wander a little out of its cell: the relative
+// coordinate simply leaves [0, cell width).  on = 0: records are absolute (every fp64 state, operator handles, domains).
+struct RelGrid {
+    double lo[3], cw[3];      // box origin, cell widths
+    int M[3];
+    int on;
+    const int *cell;          // cell of every slot (NbSystem::cell_sorted as of the sort the records belong to)
+    // Cell origins sit on ONE fixed-point grid of the box, REL_FX = 2^19 points per length unit (what fp32 resolves at the far end
+    // of a brick's tile): a tile coordinate is then (round(record x 2^19) + an INTEGER per tile cell) / 2^19, exact in fp32, and
+    // two atoms have the same separation in whichever brick's tile they meet -- F_ij = -F_ji to the bit (brick.hpp rel_tile).
+    __host__ __device__ __forceinline__ double origin_q(int d, int c) const { return rint((lo[d] + (double)c * cw[d]) * 524288.0); }   // in grid points
+    __device__ __forceinline__ void origin(int c, double &ox, double &oy, double &oz) const {
+        const int cx = c % M[0], cy = (c / M[0]) % M[1], cz = c / (M[0] * M[1]);
+        ox = origin_q(0, cx) * (1.0 / 524288.0); oy = origin_q(1, cy) * (1.0 / 524288.0); oz = origin_q(2, cz) * (1.0 / 524288.0);
+    }
+};
+constexpr float REL_FX = 524288.f, REL_IFX = 1.f / 524288.f;
+
 // read-only view of the cell-ordered atoms
 template <typename real>
 struct AtomView {
     const Rec<real> *rec;
     const float *te;   // fp32 only (fp64 keeps te inside the record)
+    RelGrid rel;       // fp32 only: cell-relative records (load_atom returns absolute coordinates, rounded to fp32)
 };
 
 __device__ __forceinline__ void load_atom(const AtomView<double> &a, int p, double &x, double &y, double &z, double &hs,
@@ -52,6 +74,11 @@ __device__ __forceinline__ void load_atom(const AtomView<float> &a, int p, float
                                           float &te) {
     Rec<float> r = a.rec[p];    // 1 x global_load_dwordx4
     x = r.x; y = r.y; z = r.z; hs = r.hs; te = a.te[p];
+    if (a.rel.on) {             // (the kernels that come through here are not the integrator's hot ones)
+        double ox, oy, oz;
+        a.rel.origin(a.rel.cell[p], ox, oy, oz);
+        x = (float)((double)x + ox); y = (float)((double)y + oy); z = (float)((double)z + oz);
+    }
 }
 
 // ------------------------------------------------------------------------------------ grid
@@ -100,9 +127,15 @@ struct UserPos {
 template <typename real>
 struct RecPos {
     const Rec<real> *r;
+    RelGrid rel;
     __device__ __forceinline__ void get(int i, real &x, real &y, real &z) const {
         Rec<real> q = r[i];
         x = q.x; y = q.y; z = q.z;
+        if (sizeof(real) == 4 && rel.on) {
+            double ox, oy, oz;
+            rel.origin(rel.cell[i], ox, oy, oz);
+            x = (real)((double)q.x + ox); y = (real)((double)q.y + oy); z = (real)((double)q.z + oz);
+        }
     }
 };
 
@@ -478,6 +511,15 @@ __device__ __forceinline__ int wrap_into_box(real &p, real lo, real len, int per
     return (int)k;
 }
 
+// cell-relative records: the periodic image of a coordinate (already relative to a cell origin) that lies next to that cell;
+// returns the box lengths removed
+__device__ __forceinline__ int rel_nearest_image(double &r, double len, int periodic) {
+    if (!periodic) return 0;
+    const double s = rint(r / len);
+    r -= s * len;
+    return (int)s;
+}
+
 // Build the cell-ordered state from caller-order arrays.  order[p] = caller id of slot p.
 template <typename real>
 __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, const int *__restrict__ order,
@@ -488,7 +530,7 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
                               int *__restrict__ perm, int *__restrict__ inv_perm, int *__restrict__ cell_sorted,
                               int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
                               long long *__restrict__ tag_out = nullptr, int ncell = 0, int *__restrict__ cstart = nullptr,
-                              const int *__restrict__ tstart = nullptr) {
+                              const int *__restrict__ tstart = nullptr, RelGrid rel_out = RelGrid{}) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     // (typed boxes and x sub-bins: the first slot of every CELL from the per-(cell, digit) starts -- rides here instead of
     // being a launch of its own)
@@ -502,6 +544,15 @@ __global__ void k_gather_user(int n, int n_owned, size_t pitch, GridP<real> g, c
     const int kz = wrap_into_box(z, g.lo[2], g.len[2], g.per[2]);
     img[p] = img_pack(kx, ky, kz);
     emdee_lj_atom a = atoms[i];
+    if (sizeof(real) == 4 && rel_out.on) {                   // cell-relative records (RelGrid)
+        double ox, oy, oz;
+        rel_out.origin(cell_of[i] / nt, ox, oy, oz);
+        double rx = (double)x - ox, ry = (double)y - oy, rz = (double)z - oz;
+        int jx = kx + rel_nearest_image(rx, (double)g.len[0], g.per[0]), jy = ky + rel_nearest_image(ry, (double)g.len[1], g.per[1]),
+            jz = kz + rel_nearest_image(rz, (double)g.len[2], g.per[2]);
+        img[p] = img_pack(jx, jy, jz);
+        x = (real)rx; y = (real)ry; z = (real)rz;
+    }
     store_rec<real>(rec, te, p, x, y, z, a.half_sigma, a.twice_sqrt_eps);
     xb[p] = x; xb[pitch + p] = y; xb[2 * pitch + p] = z;
     bool owned = i < n_owned;
@@ -530,7 +581,7 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
                                 int *__restrict__ img, int nt = 1, const long long *__restrict__ tag_in = nullptr,
                                 long long *__restrict__ tag_out = nullptr, const int *__restrict__ n_dev = nullptr,
                                 int *__restrict__ n_out = nullptr, int ncell = 0, int *__restrict__ cstart = nullptr,
-                                const int *__restrict__ tstart = nullptr) {
+                                const int *__restrict__ tstart = nullptr, RelGrid rel_in = RelGrid{}, RelGrid rel_out = RelGrid{}) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (cstart) for (int c = p; c <= ncell; c += gridDim.x * blockDim.x) cstart[c] = tstart[(size_t)c * nt];
     if (EDIT) {
@@ -544,9 +595,30 @@ __global__ void k_gather_sorted(int n, size_t pitch, GridP<real> g, const int *_
     rec_params(rec_in, te_in, o, hs, tev);
     int kx = 0, ky = 0, kz = 0;
     if (!EDIT) img_unpack(img_in[o], kx, ky, kz);
-    kx += wrap_into_box(r.x, g.lo[0], g.len[0], g.per[0]);
-    ky += wrap_into_box(r.y, g.lo[1], g.len[1], g.per[1]);
-    kz += wrap_into_box(r.z, g.lo[2], g.len[2], g.per[2]);
+    if (sizeof(real) == 4 && (rel_in.on || rel_out.on)) {
+        // cell-relative records: the absolute position in double, wrapped, then relative to the NEW cell (the cell the
+        // binning pass found from the same position rounded to fp32: should the rounding have crossed a cell boundary, the
+        // relative coordinate is a hair outside [0, width) -- as after any step)
+        double ax = (double)r.x, ay = (double)r.y, az = (double)r.z, ox, oy, oz;
+        if (rel_in.on) { rel_in.origin(rel_in.cell[o], ox, oy, oz); ax += ox; ay += oy; az += oz; }
+        kx += wrap_into_box(ax, (double)g.lo[0], (double)g.len[0], g.per[0]);
+        ky += wrap_into_box(ay, (double)g.lo[1], (double)g.len[1], g.per[1]);
+        kz += wrap_into_box(az, (double)g.lo[2], (double)g.len[2], g.per[2]);
+        if (rel_out.on) {
+            rel_out.origin(cell_of[o] / nt, ox, oy, oz); ax -= ox; ay -= oy; az -= oz;
+            // At a periodic face the binning (position rounded to fp32) and the wrap above (double) may pick different images of
+            // the same atom -- fp32(L - 1e-6) is L, i.e. cell 0, while the double stays below L: take the image next to the cell
+            // the atom was binned into (found on the GPU: an atom at z = 0 came out a whole box away from its cell, with an empty row)
+            kx += rel_nearest_image(ax, (double)g.len[0], g.per[0]);
+            ky += rel_nearest_image(ay, (double)g.len[1], g.per[1]);
+            kz += rel_nearest_image(az, (double)g.len[2], g.per[2]);
+        }
+        r.x = (real)ax; r.y = (real)ay; r.z = (real)az;
+    } else {
+        kx += wrap_into_box(r.x, g.lo[0], g.len[0], g.per[0]);
+        ky += wrap_into_box(r.y, g.lo[1], g.len[1], g.per[1]);
+        kz += wrap_into_box(r.z, g.lo[2], g.len[2], g.per[2]);
+    }
     img[p] = img_pack(kx, ky, kz);
     store_rec<real>(rec, te, p, r.x, r.y, r.z, hs, tev);
     xb[p] = r.x; xb[pitch + p] = r.y; xb[2 * pitch + p] = r.z;
@@ -903,7 +975,7 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, 
                          real *__restrict__ pos_out,
                          real *__restrict__ vel_out, real *__restrict__ frc_out, real *__restrict__ en_out,
                          real *__restrict__ vir_out, emdee_lj_atom *__restrict__ atoms_out, long long *__restrict__ tag_out,
-                         int raw) {
+                         int raw, RelGrid rel = RelGrid{}) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_total) return;
     const int id = perm[p];
@@ -912,9 +984,17 @@ __global__ void k_unsort(int n_owned, int n_total, size_t pitch, GridP<real> g, 
         Rec<real> r = rec[p];
         int kx = 0, ky = 0, kz = 0;
         if (!raw) img_unpack(img[p], kx, ky, kz);   // back to the caller's (unwrapped) image
-        pos_out[3 * (size_t)i] = r.x + (real)kx * g.len[0];
-        pos_out[3 * (size_t)i + 1] = r.y + (real)ky * g.len[1];
-        pos_out[3 * (size_t)i + 2] = r.z + (real)kz * g.len[2];
+        if (sizeof(real) == 4 && rel.on) {          // cell-relative records: origin + record + images, in double, rounded once
+            double ox, oy, oz;
+            rel.origin(rel.cell[p], ox, oy, oz);
+            pos_out[3 * (size_t)i] = (real)((double)r.x + ox + (double)kx * (double)g.len[0]);
+            pos_out[3 * (size_t)i + 1] = (real)((double)r.y + oy + (double)ky * (double)g.len[1]);
+            pos_out[3 * (size_t)i + 2] = (real)((double)r.z + oz + (double)kz * (double)g.len[2]);
+        } else {
+            pos_out[3 * (size_t)i] = r.x + (real)kx * g.len[0];
+            pos_out[3 * (size_t)i + 1] = r.y + (real)ky * g.len[1];
+            pos_out[3 * (size_t)i + 2] = r.z + (real)kz * g.len[2];
+        }
     }
     if (atoms_out) {
         emdee_lj_atom a;

@@ -178,7 +178,7 @@ struct NbSystem {
     DevBuf<Rec<real>> rec, rec2;
     DevBuf<float> te, te2;
     DevBuf<real> vel, vel2, frc, en, vir, im, im2, xb, noise;
-    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, order, count, fill, nbr, cnt, flags, img, img2;
+    DevBuf<int> perm, perm2, inv_perm, cell_of, cell_sorted, cell_sorted2, order, count, fill, nbr, cnt, flags, img, img2;
     DevBuf<int2> tmp2;                    // {id, sort key} in arrival order inside each cell (bin)
     // 64-bit ids that travel with the atoms through every sort (decomposed domains: the GLOBAL ids, owned atoms and ghosts).
     // With them the order inside a cell is by the low word of the tag, not by the local id: the cell order -- and with it the
@@ -226,7 +226,37 @@ struct NbSystem {
     }
 
     hipStream_t stream() const { return ctx->stream; }
-    AtomView<real> view() const { return AtomView<real>{rec.ptr, te.ptr}; }
+    AtomView<real> view() const { return AtomView<real>{rec.ptr, te.ptr, rel_grid(rel_now, cell_sorted.ptr)}; }
+
+    // ---- cell-relative records (kernels.hpp RelGrid): fp32 integrators on the tiled path, undivided boxes ----
+    // rel_now: what the records of the CURRENT sorted state are; decided anew at every sort (rel_wanted), the gather kernels
+    // read one representation and write the other.  EMDEE_F32_ABS=1 keeps absolute fp32 records (the A/B baseline: rounds 1-4).
+    bool rel_now = false;
+    double rel_lo[3] = {0, 0, 0}, rel_cw[3] = {1, 1, 1};
+    int rel_M[3] = {1, 1, 1};
+    bool rel_wanted() const {
+        return sizeof(real) == 4 && with_vel && !with_mass && !use_tags && !has_ghosts && path == PATH_BRICK && !tbuild_enabled &&
+               near_far_scale() <= 0.0 && std::getenv("EMDEE_F32_ABS") == nullptr;
+    }
+    RelGrid rel_grid(bool on, const int *cells) const {
+        RelGrid r{};
+        for (int d = 0; d < 3; d++) { r.lo[d] = rel_lo[d]; r.cw[d] = rel_cw[d]; r.M[d] = rel_M[d]; }
+        r.on = on ? 1 : 0;
+        r.cell = cells;
+        return r;
+    }
+    // the grid the NEXT sorted state's records will be relative to (call after configure_grid)
+    RelGrid rel_grid_next(bool on, const int *cells) const {
+        RelGrid r{};
+        for (int d = 0; d < 3; d++) { r.lo[d] = (double)grid.lo[d]; r.cw[d] = (double)grid.len[d] / (double)grid.M[d]; r.M[d] = grid.M[d]; }
+        r.on = on ? 1 : 0;
+        r.cell = cells;
+        return r;
+    }
+    void rel_commit(bool on) {
+        rel_now = on;
+        for (int d = 0; d < 3; d++) { rel_lo[d] = (double)grid.lo[d]; rel_cw[d] = (double)grid.len[d] / (double)grid.M[d]; rel_M[d] = grid.M[d]; }
+    }
 
     struct Timed {
         NbSystem *s;
@@ -308,7 +338,7 @@ struct NbSystem {
         if (velocities) { vel.ensure(3 * pitch); vel2.ensure(3 * pitch); }
         if (masses) { im.ensure(pitch); im2.ensure(pitch); }
         perm.ensure(m + 1); perm2.ensure(m + 1); inv_perm.ensure(m + 1); img.ensure(m + 1); img2.ensure(m + 1);
-        cell_of.ensure(m + 1); cell_sorted.ensure(m + 1); order.ensure(m + 1); cnt.ensure(m + 1);
+        cell_of.ensure(m + 1); cell_sorted.ensure(m + 1); cell_sorted2.ensure(m + 1); order.ensure(m + 1); cnt.ensure(m + 1);
         if (use_tags) { tag.ensure(m + 1); tag2.ensure(m + 1); }
         if (flags.ensure(32)) EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, 32 * sizeof(int), stream()));
         partial.ensure(3 * RED_MAX_BLOCKS); sums.ensure(8); stats.ensure(4);
@@ -377,6 +407,7 @@ struct NbSystem {
         detect_uniform_atoms(atoms);
         configure_grid();
         const int n = n_total;
+        const bool rel_next = rel_wanted();
         choose_subbins();
         if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms}, -1, use_tags ? tags_user : nullptr);
         else bin_untyped(UserPos<real>{pos}, nullptr, -1, use_tags ? tags_user : nullptr);
@@ -385,7 +416,8 @@ struct NbSystem {
                                grid, order.ptr, cell_of.ptr, pos, atoms, velocities, inv_mass, rec.ptr, te.ptr, xb.ptr,
                                with_vel ? vel.ptr : nullptr, with_mass ? im.ptr : nullptr, perm.ptr, inv_perm.ptr,
                                cell_sorted.ptr, img.ptr, digits(), use_tags ? tags_user : nullptr, use_tags ? tag.ptr : nullptr,
-                               (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
+                               (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr, rel_grid_next(rel_next, nullptr));
+        rel_commit(rel_next);
         // ghosts are never written by the step kernel: both position buffers carry their records (LJAtom fields)
         // from the start; their coordinates are refreshed by every halo unpack
         if (has_ghosts)
@@ -403,20 +435,24 @@ struct NbSystem {
         configure_grid();
         choose_subbins();
         const long long *tk = use_tags ? tag.ptr : nullptr;
-        if (nt > 1) bin(RecPos<real>{rec.ptr}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr}, -1, tk);
-        else bin_untyped(RecPos<real>{rec.ptr}, perm.ptr, -1, tk);
+        const RelGrid rel_in = rel_grid(rel_now, cell_sorted.ptr);   // (the cells the current records are relative to: read before the grid may change)
+        const bool rel_next = rel_wanted();
+        if (nt > 1) bin(RecPos<real>{rec.ptr, rel_in}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr}, -1, tk);
+        else bin_untyped(RecPos<real>{rec.ptr, rel_in}, perm.ptr, -1, tk);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_sorted<real, false>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
                                order.ptr, cell_of.ptr, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr,
                                with_mass ? im.ptr : nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr, xb.ptr,
                                with_vel ? vel2.ptr : nullptr, with_mass ? im2.ptr : nullptr, perm2.ptr, inv_perm.ptr,
-                               cell_sorted.ptr, img2.ptr, digits(), tk, use_tags ? tag2.ptr : nullptr, (const int *)nullptr,
-                               (int *)nullptr, (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
+                               cell_sorted2.ptr, img2.ptr, digits(), tk, use_tags ? tag2.ptr : nullptr, (const int *)nullptr,
+                               (int *)nullptr, (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr, rel_in,
+                               rel_grid_next(rel_next, nullptr));
         swap_sorted_buffers();
+        rel_commit(rel_next);
         build_list();
     }
     void swap_sorted_buffers() {
-        rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2);
+        rec.swap(rec2); te.swap(te2); perm.swap(perm2); img.swap(img2); cell_sorted.swap(cell_sorted2);
         if (with_vel) vel.swap(vel2);
         if (with_mass) im.swap(im2);
         if (use_tags) tag.swap(tag2);
@@ -449,12 +485,13 @@ struct NbSystem {
         edit_saved = EditSaved{n_total, n_owned, id_space, id_gaps, has_ghosts, has_list};
         configure_grid();
         choose_subbins();
-        if (nt > 1) bin(RecPos<real>{rec.ptr}, nullptr, RecSpecies<real>{species, rec.ptr, te.ptr}, n_items, tag.ptr, keep);
-        else bin_untyped(RecPos<real>{rec.ptr}, nullptr, n_items, tag.ptr, keep);
+        EMDEE_REQUIRE(!rel_now, EMDEE_ERR_STATE, "resort_edit: cell-relative records (decomposed domains keep absolute ones)");
+        if (nt > 1) bin(RecPos<real>{rec.ptr, RelGrid{}}, nullptr, RecSpecies<real>{species, rec.ptr, te.ptr}, n_items, tag.ptr, keep);
+        else bin_untyped(RecPos<real>{rec.ptr, RelGrid{}}, nullptr, n_items, tag.ptr, keep);
         const size_t nbins = ncell * (size_t)digits();
         hipLaunchKernelGGL((k_gather_sorted<real, true>), dim3(blocks_for(n_items, 256)), dim3(256), 0, stream(), n_items, pitch, grid,
                            order.ptr, cell_of.ptr, rec.ptr, te.ptr, vel.ptr, (const real *)nullptr, perm.ptr, img.ptr, rec2.ptr, te2.ptr,
-                           xb.ptr, vel2.ptr, (real *)nullptr, perm2.ptr, inv_perm.ptr, cell_sorted.ptr, img2.ptr, digits(), tag.ptr,
+                           xb.ptr, vel2.ptr, (real *)nullptr, perm2.ptr, inv_perm.ptr, cell_sorted2.ptr, img2.ptr, digits(), tag.ptr,
                            tag2.ptr, count.ptr + nbins, n_live_dev, (int)ncell, digits() > 1 ? cstart.ptr : nullptr, count.ptr);
         swap_sorted_buffers();
         edit_n_plan = n_total;
@@ -536,6 +573,8 @@ struct NbSystem {
                     a.te4[i * 2 + j] = (real)ti * (real)tj;
                 }
         }
+        a.rel = rel_now ? 1 : 0;
+        for (int d = 0; d < 3; d++) { a.rcw[d] = rel_cw[d]; a.rlo[d] = rel_lo[d]; }
         a.far_skip = far_skip_active() ? 1 : 0;
         a.far_word = flags.ptr + 16;
         a.thr2_near = (real)(0.25 * near_delta() * near_delta());
@@ -1479,7 +1518,8 @@ struct NbSystem {
         const int *map = ids_map();
         hipLaunchKernelGGL((k_unsort<real>), dim3(blocks_for(n_total, 256)), dim3(256), 0, stream(), n_owned, n_total, pitch,
                            grid, img.ptr, perm.ptr, map, rec.ptr, te.ptr, with_vel ? vel.ptr : nullptr, frc.ptr, en.ptr, vir.ptr,
-                           use_tags ? tag.ptr : nullptr, pos, velocities, forces, energies, virials, atoms_out, tags_out, raw ? 1 : 0);
+                           use_tags ? tag.ptr : nullptr, pos, velocities, forces, energies, virials, atoms_out, tags_out, raw ? 1 : 0,
+                           rel_grid(rel_now, cell_sorted.ptr));
     }
 
     // operator path: does the cached list still cover these caller positions?

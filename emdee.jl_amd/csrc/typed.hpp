@@ -292,6 +292,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
         org[1] = a.g.lo[1] + (real)(byi * BY) * (a.g.len[1] / (real)a.g.M[1]);
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
+    __shared__ float s_relc[sizeof(real) == 4 ? Shape::TX + Shape::TY + Shape::TZ : 1];   // cell-relative records (brick.hpp rel_cell_const)
+    if (sizeof(real) == 4 && a.rel) {
+        rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
+        __syncthreads();
+    }
     int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS], own_q[OWN_REGS];
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
@@ -307,9 +312,16 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
         const int sh = T.shift[tc % NTC];
         const Rec<real> r = a.rec[gp];
         float4 q;
-        q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
-        q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
-        q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
+        if (sizeof(real) == 4 && a.rel) {                     // cell-relative records (brick.hpp rel_tile)
+            const int uc = tc % NTC;
+            q.x = (float)rel_tile(r.x, s_relc[uc % TX]);
+            q.y = (float)rel_tile(r.y, s_relc[TX + (uc / TX) % TY]);
+            q.z = (float)rel_tile(r.z, s_relc[TX + TY + uc / (TX * TY)]);
+        } else {
+            q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
+            q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
+            q.z = (float)((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]);
+        }
         q.w = __int_as_float(gp);
         if (EMDEE_BOUND(BS_TYPED_TILE, s, a.tile_cap)) tile[s] = q;
     });
@@ -562,6 +574,11 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
     }
     // fp32 boxes: brick-relative tile coordinates (brick.hpp k_brick)
     constexpr bool REL = sizeof(real) == 4;
+    __shared__ float s_relc[REL ? Shape::TX + Shape::TY + Shape::TZ : 1];   // cell-relative records: brick.hpp rel_cell_const
+    if (REL && a.rel) {
+        rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
+        __syncthreads();
+    }
     double org[3] = {0.0, 0.0, 0.0};
     if (REL) {
         org[0] = (double)a.g.lo[0] + (double)(bxi * Shape::BX) * ((double)a.g.len[0] / (double)a.g.M[0]);
@@ -572,7 +589,11 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc % NTC];
         Rec<real> r = a.rec[gp];
-        if (REL) {
+        if (REL && a.rel) {                                   // cell-relative records: fixed-point tile coordinates (brick.hpp k_brick)
+            const int uc = tc % NTC;
+            r.x = (real)rel_tile(r.x, s_relc[uc % Shape::TX]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + (uc / Shape::TX) % Shape::TY]);
+            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + uc / (Shape::TX * Shape::TY)]);
+        } else if (REL) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);
             r.z = (real)(((double)r.z + (double)(((sh >> 4) & 3) - 1) * (double)a.g.len[2]) - org[2]);
