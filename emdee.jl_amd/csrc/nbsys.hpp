@@ -74,7 +74,7 @@ struct Scanner {
 };
 
 // ---- brick kernel variants (shape, workgroup size, lanes per atom); variant 0 is the default ----
-constexpr int BRICK_VARIANTS = 9;
+constexpr int BRICK_VARIANTS = 10;
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <int V>
@@ -91,6 +91,10 @@ template <> struct BrickVariant<6> { using Shape = BrickShape<3, 3, 2>; static c
 // are 46 pair steps per lane -- amortise a round's fixed work over 16 atoms per wavefront instead of 8)
 template <> struct BrickVariant<7> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 4, GB = 8; };
 template <> struct BrickVariant<8> { using Shape = BrickShape<4, 2, 2>; static constexpr int THREADS = 1024, G = 8, GB = G; };
+// (9, round 5: two-species boxes with long rows on bricks of 2 x 2 x 2 cells -- a tile of 64 cells, ~2850 records at rc = 3.5 sigma,
+// fits TWO 512-thread workgroups on a CU where variant 7's 96-cell tile leaves room for one of 1024: while one workgroup stages
+// its tile or is being replaced, the other computes)
+template <> struct BrickVariant<9> { using Shape = BrickShape<2, 2, 2>; static constexpr int THREADS = 512, G = 4, GB = 8; };
 
 template <class F>
 static inline void with_brick_variant(int v, F &&f) {
@@ -105,6 +109,7 @@ static inline void with_brick_variant(int v, F &&f) {
 #endif
         case 7: f(BrickVariant<7>{}); break;
         case 8: f(BrickVariant<8>{}); break;
+        case 9: f(BrickVariant<9>{}); break;
         default: f(BrickVariant<0>{}); break;
     }
 }
@@ -597,9 +602,11 @@ struct NbSystem {
     // than FORCES run the all-outputs kernel
     bool typed_active = false;
     template <class V>
-    static constexpr bool typed_variant() { return std::is_same<V, BrickVariant<0>>::value || std::is_same<V, BrickVariant<7>>::value; }
+    static constexpr bool typed_variant() {
+        return std::is_same<V, BrickVariant<0>>::value || std::is_same<V, BrickVariant<7>>::value || std::is_same<V, BrickVariant<9>>::value;
+    }
     template <class V>
-    static constexpr int typed_min_stride() { return (typed_prefetch_blocks(V::G, V::THREADS) + 1) * EPL * V::G; }
+    static constexpr int typed_min_stride() { return (typed_prefetch_blocks(V::G, V::THREADS, V::Shape::NOC) + 1) * EPL * V::G; }
     template <class V, int MODE, int BM>
     void launch_typed_kernel() {
         if constexpr (typed_variant<V>()) {
@@ -810,7 +817,7 @@ struct NbSystem {
 #ifdef EMDEE_EXPERIMENTS
             if (tbuild_active<V>()) ok = brick_tbuild_lds_bytes<typename V::Shape, V::THREADS, TB_NPAIR>(tile_cap, own_cap, stride) <= LDS_LIMIT;
 #endif
-            if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB) <= LDS_LIMIT;
+            if (typed_active) ok = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, V::G) <= LDS_LIMIT;
         });
         return ok;
     }
@@ -846,14 +853,40 @@ struct NbSystem {
             // Measured (profiles/README.md, round 3): at rc = 3.5 sigma 190.7 -> 218.0 steps/s in fp64 and 233.8 -> 324.2 in fp32; at
             // rc = 2.5 (variant 0, rows of ~37 entries per species) the 18 short candidate rows cost the build more than the
             // pair loop gains, 453.9 -> 419.1: short-row boxes keep the general-species kernels (EMDEE_TYPED_ALL=1 overrides)
-            const int keep = variant, cand = (variant == 8 && !variant_forced) ? 7 : variant;
-            if (cand == 7 || (cand == 0 && std::getenv("EMDEE_TYPED_ALL") != nullptr)) {
+            // Long rows (the general kernels chose 1024-thread workgroups): first the small bricks of variant 9, two 512-thread
+            // workgroups per CU -- if its tile and both kernels fit half a CU's LDS --, then variant 7 (EMDEE_TYPED_BRICKS=7: the
+            // A/B baseline).  Short rows: variant 0, on request only.
+            const int keep = variant;
+            int cands[2] = {-1, -1};
+            if (variant == 8 && !variant_forced) {
+                const char *tb = std::getenv("EMDEE_TYPED_BRICKS");
+                const bool only7 = tb != nullptr && std::atoi(tb) == 7;
+                cands[0] = only7 ? 7 : 9;
+                cands[1] = only7 ? -1 : 7;
+            } else if (variant == 7 || variant == 9 || (variant == 0 && std::getenv("EMDEE_TYPED_ALL") != nullptr)) {
+                cands[0] = variant;
+            }
+            const int keep_maxima[3] = {plan_maxima[0], plan_maxima[1], plan_maxima[2]};
+            for (int ci = 0; ci < 2 && !typed_active; ci++) {
+                const int cand = cands[ci];
+                if (cand < 0) continue;
                 variant = cand;
-                if (cand != keep) { plan_geometry(); plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]); }
+                bool same_shape = false;
+                with_brick_variant(keep, [&](auto kv) {
+                    with_brick_variant(cand, [&](auto cv) { same_shape = std::is_same<typename decltype(kv)::Shape, typename decltype(cv)::Shape>::value; });
+                });
+                if (same_shape) {
+                    for (int k = 0; k < 3; k++) plan_maxima[k] = keep_maxima[k];   // (a candidate of another shape left its own)
+                    plan_geometry();
+                    plan_sizes(keep_maxima[0], keep_maxima[1], keep_maxima[2]);
+                }
+                else plan_bricks();                                  // another brick shape: its own population maxima (a read-back; plans are rare)
                 with_brick_variant(variant, [&](auto v) {
                     using V = decltype(v);
                     if constexpr (typed_variant<V>()) {
                         using S = typename V::Shape;
+                        // (the planes hold typed_slots records: do not let the headroom alone push a tile past them)
+                        if (plan_maxima[0] + 1 <= typed_slots<S, V::THREADS>()) tile_cap = std::min(tile_cap, typed_slots<S, V::THREADS>());
                         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 8, 0, sizeof(int), stream()));
                         hipLaunchKernelGGL((k_typed_span_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
                                            grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], tstart(), flags.ptr + 8);
@@ -865,12 +898,14 @@ struct NbSystem {
                             st = std::max(stride, typed_min_stride<V>()) + row_block;   // + the padding between the two segments
                             st = (st + row_block - 1) / row_block * row_block;
                         }
-                        const bool ok = tile_cap <= typed_slots<V::THREADS>() && span <= 16 * V::GB &&
-                                        typed_force_lds_bytes<real, S, V::THREADS>(own_cap) <= LDS_LIMIT &&
-                                        typed_build_lds_bytes<S, V::THREADS>(tile_cap, own_cap, st, V::GB) <= LDS_LIMIT;
+                        const size_t lds_f = typed_force_lds_bytes<real, S, V::THREADS>(own_cap),
+                                     lds_b = typed_build_lds_bytes<S, V::THREADS>(tile_cap, own_cap, st, V::GB, V::G);
+                        // (variant 9 exists to put two workgroups on a CU: it is taken only where both kernels leave room for that)
+                        const size_t room = cand == 9 ? LDS_LIMIT / 2 - 128 : LDS_LIMIT;   // (- the kernels' static LDS)
+                        const bool ok = tile_cap <= typed_slots<S, V::THREADS>() && span <= 16 * V::GB && lds_f <= room && lds_b <= room;
                         if (std::getenv("EMDEE_DEBUG_PLAN"))
-                            std::fprintf(stderr, "emdee plan: two species, longest 3-cell span of one species %d, stride %d, typed kernels %s\n", span, st,
-                                         ok ? "on" : "off");
+                            std::fprintf(stderr, "emdee plan: two species, variant %d: tile_cap %d (max %d), own_cap %d, longest 3-cell span of one species %d, stride %d, LDS force %zu build %zu: typed kernels %s\n",
+                                         cand, tile_cap, plan_maxima[0], own_cap, span, st, lds_f, lds_b, ok ? "on" : "off");
                         if (ok) {
                             typed_active = true;
                             stride = st;
@@ -879,11 +914,10 @@ struct NbSystem {
                         }
                     }
                 });
-                if (!typed_active && cand != keep) {
-                    variant = keep;
-                    plan_geometry();
-                    plan_sizes(plan_maxima[0], plan_maxima[1], plan_maxima[2]);
-                }
+            }
+            if (!typed_active && variant != keep) {
+                variant = keep;
+                plan_bricks();
             }
         }
         if (!typed_active) typed_stride = false;
@@ -957,7 +991,7 @@ struct NbSystem {
                                                BT::bytes(0), stream(), ta);
                             btab_valid = true;
                             auto kernel = k_typed_build<real, typename V::Shape, V::THREADS, V::GB, V::G>;
-                            lds_build_bytes = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB);
+                            lds_build_bytes = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, V::G);
                             allow_big_lds(kernel, lds_build_bytes);
                             hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(), brick_args());
                             return;

@@ -29,13 +29,19 @@ constexpr int TNT = 2;   // species of a typed box
 // planes of a typed tile: records per plane (compile time: the three reads of a neighbour share one address register).
 // 512-thread workgroups keep the single-species pitch (three workgroups per CU); 1024-thread ones -- long cutoffs: the
 // rc = 3.5 sigma tile holds ~4400 records -- take one workgroup per CU and 4608 records.
-template <typename real, int THREADS>
-constexpr int typed_pitch() { return (THREADS >= 1024 ? 4608 : SOA_SLOTS) + ((sizeof(real) == 8 && EMDEE_SOA_PAD) ? 1 : 0); }
-template <int THREADS>
-constexpr int typed_slots() { return THREADS >= 1024 ? 4608 : SOA_SLOTS; }
+// (round 5: bricks of 2 x 2 x 2 cells -- 64 tile cells, 2916 records at rc = 3.5 sigma and rho* = 0.8 before the melt's fluctuations; 3104 slots are what half a
+// CU's LDS holds in fp64 next to the tables -- in 512-thread workgroups, TWO per CU:
+// with one 1024-thread workgroup per CU the vector units idled 30 % of the kernel -- nothing computes while a tile is staged
+// or a workgroup is replaced, profiles/r05/valu_f64_mix_rc3.5.txt)
+template <class Shape, int THREADS>
+constexpr int typed_slots() { return THREADS >= 1024 ? 4608 : (Shape::NOC == 8 ? 3104 : SOA_SLOTS); }
+template <typename real, class Shape, int THREADS>
+constexpr int typed_pitch() { return typed_slots<Shape, THREADS>() + ((sizeof(real) == 8 && EMDEE_SOA_PAD) ? 1 : 0); }
 // index blocks of a row (= of its species-0 segment) fetched one atom ahead: two of 32 entries where rows are short, four where
-// the workgroup is the long-row one (rc = 3.5 sigma: ~92 neighbours per species)
-constexpr int typed_prefetch_blocks(int G, int THREADS) { return (EPL * G) >= 128 ? 1 : ((G == 4 && THREADS >= 1024) ? 4 : 2); }
+// the workgroup is a long-row one (rc = 3.5 sigma: ~92 neighbours per species; NOC = own cells of the brick shape)
+constexpr int typed_prefetch_blocks(int G, int THREADS, int NOC = 16) { return (EPL * G) >= 128 ? 1 : ((G == 4 && (THREADS >= 1024 || NOC == 8)) ? 4 : 2); }
+// entries the build's LDS row buffer holds per atom: ONE segment (the two species are emitted and flushed one after the other)
+constexpr int typed_seg_cap(int stride, int GL) { return ((stride / 2) + EPL * GL - 1) / (EPL * GL) * (EPL * GL); }
 
 template <class Shape, int THREADS>
 struct TypedTables {
@@ -65,11 +71,11 @@ struct TypedTables {
 
 template <typename real, class Shape, int THREADS>
 static inline size_t typed_force_lds_bytes(int own_cap) {
-    return (((size_t)3 * typed_pitch<real, THREADS>() * sizeof(real) + 15) & ~(size_t)15) + TypedTables<Shape, THREADS>::bytes(own_cap) + 64;
+    return (((size_t)3 * typed_pitch<real, Shape, THREADS>() * sizeof(real) + 15) & ~(size_t)15) + TypedTables<Shape, THREADS>::bytes(own_cap) + 64;
 }
 template <class Shape, int THREADS>
-static inline size_t typed_build_lds_bytes(int tile_cap, int own_cap, int stride, int G) {
-    return (size_t)tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * stride * 2 +
+static inline size_t typed_build_lds_bytes(int tile_cap, int own_cap, int stride, int G, int GL = 4) {
+    return (size_t)tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * typed_seg_cap(stride, GL) * 2 +
            (size_t)(Shape::NOC + 1) * 9 * TNT * 8;
 }
 
@@ -272,7 +278,7 @@ __global__ void k_typed_span_max(BrickGrid bg, int Mx, int My, int Mz, int px, i
 // per species.  Row of atom p: entries [0, n0) = neighbours of species 0, [S1, S1 + n1) = neighbours of species 1 with
 // S1 = n0 rounded up to a whole block of 8 GL entries; cnt[p] = n0 | n1 << 16.
 template <typename real, class Shape, int THREADS, int G, int GL>
-__global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_build(BrickArgs<real> a) {
+__global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4)) void k_typed_build(BrickArgs<real> a) {   // (2 x 2 x 2 bricks: two 512-thread workgroups per CU = 4 waves per SIMD)
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC, NOC = Shape::NOC;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
     static_assert(G == 8, "typed build: 8 lanes per atom");
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
     // candidate rows per own cell: for each neighbour species the 9 tile rows of 3 cells around it, {first tile slot, slots};
     // entry NOC is empty (atoms that own no row)
     unsigned char *after = s_dyn + (size_t)a.tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(a.own_cap);
-    int2 *rtab = reinterpret_cast<int2 *>(after + (size_t)NGROUPS * a.stride * 2);
+    int2 *rtab = reinterpret_cast<int2 *>(after + (size_t)NGROUPS * typed_seg_cap(a.stride, GL) * 2);
     for (int i = tid; i < (NOC + 1) * NR2; i += THREADS) {
         const int oc = i / NR2, tr = i % NR2, t = tr / NROWS, r = tr % NROWS;
         int2 v = make_int2(0, 0);
@@ -355,13 +361,14 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
     const int gl = lane & (G - 1);
     const int gid = (tid / WAVE) * (WAVE / G) + lane / G;
     const float rl2 = (float)a.rlist2;
-    unsigned short *rowbuf = reinterpret_cast<unsigned short *>(after) + (size_t)gid * a.stride;
+    constexpr int BLKL = EPL * GL;                           // entries per lane-major block of the force kernels' rows
+    const int segcap = typed_seg_cap(a.stride, GL);          // the row buffer holds ONE segment (round 5: half the LDS of a whole row)
+    unsigned short *rowbuf = reinterpret_cast<unsigned short *>(after) + (size_t)gid * segcap;
     const unsigned ustride = (unsigned)a.stride;
     const uint4 fill = make_uint4(0, 0, 0, 0);               // sentinel slot 0
     float nrl2 = -rl2, margin_v = a.margin;
     asm volatile("" : "+v"(nrl2), "+v"(margin_v));
     const int kshift = a.idx_shift + LOG2G;                  // bit k of a field is slot cb + k G
-    constexpr int BLKL = EPL * GL;                           // entries per lane-major block of the force kernels' rows
     for (int ob = 0; ob < n_own; ob += NGROUPS) {            // wave-uniform trip count
         const int o = ob + gid;
         const bool have = o < n_own;
@@ -370,7 +377,6 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
         const bool act = have && ((info.y >> 16) & 1) != 0;   // ghosts own no row
         const float4 qi = tile[ti];
         unsigned short *row = a.nbr + (size_t)p * a.stride;
-        for (int c = gl * EPL; c < a.stride; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
         const int2 *rt = rtab + (act ? oc : NOC) * NR2;
         // wave-uniform trip counts of the 18 rows: per species, lane gl of every group holds the chunk length of row gl
         // (row 8 apart), three max steps combine the groups of the wavefront
@@ -497,10 +503,14 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
         const int incl0 = group_prefix(mine0), incl1 = group_prefix(mine1);
         const int total0 = __shfl(incl0, lane | (G - 1)), total1 = __shfl(incl1, lane | (G - 1));
         const int S1 = (total0 + BLKL - 1) / BLKL * BLKL;        // species-1 segment: from the next block boundary on
-        unsigned short *const ep_last = rowbuf + (ustride - 1u);
+        unsigned short *const ep_last = rowbuf + (unsigned)(segcap - 1);
+        // One segment at a time through the row buffer: fill with sentinels, emit the species' hits, flush its blocks of the
+        // row -- [0, S1) for species 0, [S1, stride) for species 1 (whatever lies behind the last entry is sentinels: a lane
+        // of the force kernel walks as far as the longest row of its wavefront)
 #pragma unroll
         for (int t = 0; t < TNT; t++) {
-            unsigned short *ep = rowbuf + (unsigned)(t == 0 ? incl0 - mine0 : S1 + incl1 - mine1);
+            for (int c = gl * EPL; c < segcap; c += G * EPL) *reinterpret_cast<uint4 *>(rowbuf + c) = fill;
+            unsigned short *ep = rowbuf + (unsigned)(t == 0 ? incl0 - mine0 : incl1 - mine1);
 #pragma unroll
             for (int w = 0; w < WPT; w++) {
                 unsigned W = word[t * WPT + w];
@@ -516,26 +526,31 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
                     ep++;
                 }
             }
+            if (have && EMDEE_BOUND(BS_TYPED_ROW, p, a.n)) {
+                const int lo = t == 0 ? 0 : S1, hi = t == 0 ? min(S1, a.stride) : a.stride;
+                // (left to itself the compiler interleaves two trips of this loop behind a run-time alias check and splits each
+                // 16-byte store into four: 130 instructions per atom where 40 do -- the flush was 0.32 ms of the build for that)
+                EMDEE_PLAIN_LOOP
+                for (int c = lo + gl * EPL; c < hi; c += G * EPL) {
+                    const int cs = c - lo;                    // position inside the segment
+                    uint4 q = fill;
+                    if (cs < segcap) {
+                        const unsigned short *src = rowbuf + (cs / BLKL) * BLKL + (cs % BLKL) / EPL;   // entries src[GL t], t = 0..7
+                        q.x = (unsigned)src[0 * GL] | ((unsigned)src[1 * GL] << 16);
+                        q.y = (unsigned)src[2 * GL] | ((unsigned)src[3 * GL] << 16);
+                        q.z = (unsigned)src[4 * GL] | ((unsigned)src[5 * GL] << 16);
+                        q.w = (unsigned)src[6 * GL] | ((unsigned)src[7 * GL] << 16);
+                    }
+                    *reinterpret_cast<uint4 *>(row + c) = q;
+                }
+            }
         }
-        if (have && EMDEE_BOUND(BS_TYPED_ROW, p, a.n)) {
-            // (left to itself the compiler interleaves two trips of this loop behind a run-time alias check and splits each
-            // 16-byte store into four: 130 instructions per atom where 40 do -- the flush was 0.32 ms of the build for that)
-            EMDEE_PLAIN_LOOP
-            for (int c = gl * EPL; c < a.stride; c += G * EPL) {
-                const unsigned short *src = rowbuf + (c / BLKL) * BLKL + (c % BLKL) / EPL;   // entries src[GL t], t = 0..7
-                uint4 q;
-                q.x = (unsigned)src[0 * GL] | ((unsigned)src[1 * GL] << 16);
-                q.y = (unsigned)src[2 * GL] | ((unsigned)src[3 * GL] << 16);
-                q.z = (unsigned)src[4 * GL] | ((unsigned)src[5 * GL] << 16);
-                q.w = (unsigned)src[6 * GL] | ((unsigned)src[7 * GL] << 16);
-                *reinterpret_cast<uint4 *>(row + c) = q;
-            }
-            if (gl == G - 1) {
-                const unsigned need = (unsigned)(S1 + total1);       // slots the row takes (total1 == 0: just the first segment)
-                const bool fits = need <= ustride && total0 <= 0xffff && total1 <= 0xffff;
-                a.cnt[p] = (act && fits) ? (total0 | (total1 << 16)) : 0;
-                if (!fits) atomicMax(&a.flags[0], (int)max(need, ustride + 1u));
-            }
+        if (have && gl == G - 1 && EMDEE_BOUND(BS_TYPED_ROW, p, a.n)) {
+            const unsigned need = (unsigned)(S1 + total1);           // slots the row takes (total1 == 0: just the first segment)
+            const bool fits = need <= ustride && total0 <= segcap && total1 <= segcap;
+            a.cnt[p] = (act && fits) ? (total0 | (total1 << 16)) : 0;
+            // (a segment longer than the row buffer asks for a longer stride like a row that does not fit: the buffer follows it)
+            if (!fits) atomicMax(&a.flags[0], (int)max(max(need, ustride + 1u), 2u * (unsigned)max(total0, total1) + (unsigned)BLKL));
         }
     }
 }
@@ -543,9 +558,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? 6 : 4)) void k_typed_bui
 // ------------------------------------------------------------------------------------ force / stats / fused step
 // k_brick's single-species coordinate-plane kernel run over the two segments of a row, each with its own pair constants.
 template <typename real, class Shape, int THREADS, int G, int MODE, int BITMASK>
-__global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
+__global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(BrickArgs<real> a) {   // (2 x 2 x 2 bricks: <= 128 VGPRs, two workgroups per CU)
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G), BLK = EPL * G, NTC = Shape::NTC, NOC = Shape::NOC;
-    constexpr int PITCH = typed_pitch<real, THREADS>(), PLANE_BYTES = PITCH * (int)sizeof(real);
+    constexpr int PITCH = typed_pitch<real, Shape, THREADS>(), PLANE_BYTES = PITCH * (int)sizeof(real);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     real *plane = reinterpret_cast<real *>(s_dyn);                          // x | y | z, PITCH records apart
     const unsigned char *plane_b = s_dyn;
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(THREADS) void k_typed(BrickArgs<real> a) {
     unsigned long long st_entries = 0, st_inside = 0;
     int st_max = 0;
     // the first NPF blocks of a row (= of its species-0 segment) are prefetched one atom ahead
-    constexpr int NPF = typed_prefetch_blocks(G, THREADS);
+    constexpr int NPF = typed_prefetch_blocks(G, THREADS, Shape::NOC);
     struct IdxBuf { uint4 q[NPF]; };
     auto fetch = [&](int o) {
         IdxBuf b;

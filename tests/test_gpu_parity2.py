@@ -371,10 +371,18 @@ def test_two_species_boxes_take_the_typed_kernels(emdee, oracle, dev, capfd, mon
     for k in ("f", "e", "w", "f1"):
         assert np.abs(a[k] - b[k]).max() <= tol * np.abs(b[k]).max(), k
     assert np.abs(a["f1"] - a["f"]).max() <= tol * np.abs(a["f"]).max()
-    assert a["pairs"] == b["pairs"] and a["md_pairs"] == b["md_pairs"]
-    assert a["stats"]["listed"] == b["stats"]["listed"] and a["stats"]["max_count"] == b["stats"]["max_count"]
+    # Float32 records are relative to their cell and tile coordinates relative to the tile's first cell: at rc = 3.5 the typed
+    # kernels work on 2 x 2 x 2-cell bricks and the general-species ones on 4 x 2 x 2, so a pair within one rounding of r_c or
+    # of r_list may fall on different sides in the two (Float64, and Float32 on equal bricks: identical)
+    slack = 4 if (dtype == np.float32 and rc == 3.5) else 0
+    assert abs(a["pairs"] - b["pairs"]) <= slack and abs(a["md_pairs"] - b["md_pairs"]) <= slack
+    assert abs(a["stats"]["listed"] - b["stats"]["listed"]) <= slack and abs(a["stats"]["max_count"] - b["stats"]["max_count"]) <= (1 if slack else 0)
+    differing = 0
     for i in range(N):
-        assert np.array_equal(a["rows"][i], b["rows"][i]), "row %d: typed and general-species builds disagree" % i
+        if not np.array_equal(a["rows"][i], b["rows"][i]):
+            differing += 1
+            assert differing <= 2 * slack, "row %d: typed and general-species builds disagree" % i
+            assert len(np.setxor1d(a["rows"][i], b["rows"][i])) <= 2
     dx = a["x12"] - b["x12"]
     assert np.abs(dx - L * np.rint(dx / L)).max() < (1e-10 if dtype == np.float64 else 2e-4)
     if dtype == np.float64:
