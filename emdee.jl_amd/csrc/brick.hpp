@@ -148,6 +148,7 @@ struct BrickArgs {
     int refmath;
     // typed boxes (two species, typed.hpp): per-(cell, species) starts and the pair constants sigma_ij^2, 4 eps_ij, [ti * 2 + tj]
     const int *tstart;
+    int tdig = 1;    // words of tstart per (cell, species) block: 4 when a two-species box is sorted by x quarter as well
     real tsig2[4], te4[4];
     // x sub-bins (kernels.hpp XSubBin; untyped boxes): nsub = 4 when the sort orders a cell's atoms by quarter, sub_k = K,
     // fstart = first slot of every (cell, sub-bin) block, bsub = per brick and tile cell the three inner boundaries of the

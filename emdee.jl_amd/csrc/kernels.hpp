@@ -215,6 +215,13 @@ struct RecSpecies<float> {
     const float *te;
     __device__ __forceinline__ int of(int i) const { return species_of(t, species_key(rec[i].hs, te[i])); }
 };
+// two-species boxes whose build takes x sub-bins (typed.hpp): digit = species * S + quarter
+template <class Spc, class Sub>
+struct SpeciesSub {
+    Spc spc;
+    Sub sub;
+    __device__ __forceinline__ int of(int i) const { return spc.of(i) * sub.S + sub.of(i); }
+};
 // distinct LJAtom values of a box, at most MAX_SPECIES: tab[0..3] = keys in order of arrival (EMPTY = all ones),
 // tab[4] != 0 if there are more.  Almost every thread finds its key with device-scope loads; the atomics are for the
 // first few arrivals.

@@ -207,7 +207,11 @@ struct NbSystem {
     // untyped boxes on the brick path: a cell's atoms ordered by quarter along x (kernels.hpp XSubBin), digit = cell * nsub + quarter
     int nsub = 1;
     bool subbins_enabled = std::getenv("EMDEE_NO_SUBBINS") == nullptr && exp_env("EMDEE_NO_BRICK_TABLES") == nullptr;
-    int digits() const { return nt > 1 ? nt : nsub; }
+    // two-species boxes on the brick path (round 5): the typed build takes the same quarters, digit = (cell * 2 + species) * 4 + quarter
+    // (EMDEE_TYPED_SUBBINS=0: the (cell, species) order of rounds 3-4, the A/B baseline)
+    int tsub = 1;
+    bool typed_subbins_enabled = std::getenv("EMDEE_TYPED_SUBBINS") == nullptr || std::atoi(std::getenv("EMDEE_TYPED_SUBBINS")) != 0;
+    int digits() const { return nt > 1 ? nt * tsub : nsub; }
     DevBuf<int> bsub;
     bool typed_enabled = std::getenv("EMDEE_NO_TYPED") == nullptr;
     DevBuf<int> cstart;
@@ -386,7 +390,16 @@ struct NbSystem {
         return std::max(-1, (int)std::floor(4.0 * (1.0 - rlist * (1.0 + margin) / cx)));
     }
     // sub-bins only where the round-robin two-phase build can use them: the tiled path of an untyped box
-    void choose_subbins() { nsub = (subbins_enabled && path == PATH_BRICK && nt == 1 && n_total > 0) ? 4 : 1; }
+    void choose_subbins() {
+        nsub = (subbins_enabled && path == PATH_BRICK && nt == 1 && n_total > 0) ? 4 : 1;
+        tsub = (subbins_enabled && typed_subbins_enabled && typed_enabled && path == PATH_BRICK && nt == 2 && n_total > 0) ? 4 : 1;
+    }
+    template <class Src, class Spc>
+    void bin_species(Src src, const int *key, Spc spc, int n_items = -1, const long long *tagkey = nullptr, const unsigned char *keep = nullptr) {
+        using Sub = XSubBin<real, Src>;
+        if (tsub > 1) bin(src, key, SpeciesSub<Spc, Sub>{spc, Sub{src, grid.lo[0], grid.len[0], grid.M[0], grid.per[0], tsub}}, n_items, tagkey, keep);
+        else bin(src, key, spc, n_items, tagkey, keep);
+    }
     template <class Src>
     void bin_untyped(Src src, const int *key, int n_items = -1, const long long *tagkey = nullptr, const unsigned char *keep = nullptr) {
         if (nsub > 1) bin(src, key, XSubBin<real, Src>{src, grid.lo[0], grid.len[0], grid.M[0], grid.per[0], nsub}, n_items, tagkey, keep);
@@ -414,7 +427,7 @@ struct NbSystem {
         const int n = n_total;
         const bool rel_next = rel_wanted();
         choose_subbins();
-        if (nt > 1) bin(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms}, -1, use_tags ? tags_user : nullptr);
+        if (nt > 1) bin_species(UserPos<real>{pos}, nullptr, UserSpecies{species, atoms}, -1, use_tags ? tags_user : nullptr);
         else bin_untyped(UserPos<real>{pos}, nullptr, -1, use_tags ? tags_user : nullptr);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_user<real>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, n_owned, pitch,
@@ -442,7 +455,7 @@ struct NbSystem {
         const long long *tk = use_tags ? tag.ptr : nullptr;
         const RelGrid rel_in = rel_grid(rel_now, cell_sorted.ptr);   // (the cells the current records are relative to: read before the grid may change)
         const bool rel_next = rel_wanted();
-        if (nt > 1) bin(RecPos<real>{rec.ptr, rel_in}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr}, -1, tk);
+        if (nt > 1) bin_species(RecPos<real>{rec.ptr, rel_in}, perm.ptr, RecSpecies<real>{species, rec.ptr, te.ptr}, -1, tk);
         else bin_untyped(RecPos<real>{rec.ptr, rel_in}, perm.ptr, -1, tk);
         if (n > 0)
             hipLaunchKernelGGL((k_gather_sorted<real, false>), dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, pitch, grid,
@@ -491,7 +504,7 @@ struct NbSystem {
         configure_grid();
         choose_subbins();
         EMDEE_REQUIRE(!rel_now, EMDEE_ERR_STATE, "resort_edit: cell-relative records (decomposed domains keep absolute ones)");
-        if (nt > 1) bin(RecPos<real>{rec.ptr, RelGrid{}}, nullptr, RecSpecies<real>{species, rec.ptr, te.ptr}, n_items, tag.ptr, keep);
+        if (nt > 1) bin_species(RecPos<real>{rec.ptr, RelGrid{}}, nullptr, RecSpecies<real>{species, rec.ptr, te.ptr}, n_items, tag.ptr, keep);
         else bin_untyped(RecPos<real>{rec.ptr, RelGrid{}}, nullptr, n_items, tag.ptr, keep);
         const size_t nbins = ncell * (size_t)digits();
         hipLaunchKernelGGL((k_gather_sorted<real, true>), dim3(blocks_for(n_items, 256)), dim3(256), 0, stream(), n_items, pitch, grid,
@@ -563,7 +576,7 @@ struct NbSystem {
         a.uni_sigma2 = (real)uni_sigma2; a.uni_e4 = (real)uni_e4;
         a.uni = make_uni<real>(model, (real)uni_sigma, (real)uni_e4);
         a.idx_shift = idx_shift;
-        a.tstart = tstart();
+        a.tstart = tstart(); a.tdig = nt > 1 ? tsub : 1;
         a.nsub = nsub; a.fstart = tstart(); a.bsub = nsub > 1 ? bsub.ptr : nullptr;
         a.sub_k = sub_k();
         for (int q = 0; q < 4; q++) { a.tsig2[q] = (real)0; a.te4[q] = (real)0; }
@@ -889,7 +902,7 @@ struct NbSystem {
                         if (plan_maxima[0] + 1 <= typed_slots<S, V::THREADS>()) tile_cap = std::min(tile_cap, typed_slots<S, V::THREADS>());
                         EMDEE_HIP_CHECK(hipMemsetAsync(flags.ptr + 8, 0, sizeof(int), stream()));
                         hipLaunchKernelGGL((k_typed_span_max<S>), dim3(blocks_for(bgrid.nbricks, 256)), dim3(256), 0, stream(), bgrid,
-                                           grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], tstart(), flags.ptr + 8);
+                                           grid.M[0], grid.M[1], grid.M[2], grid.per[0], grid.per[1], grid.per[2], tstart(), flags.ptr + 8, tsub);
                         EMDEE_HIP_CHECK(hipMemcpyAsync(ctx->host_flags + 8, flags.ptr + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
                         EMDEE_HIP_CHECK(hipStreamSynchronize(stream()));
                         const int span = ctx->host_flags[8];
@@ -987,13 +1000,19 @@ struct NbSystem {
                             btab.ensure((size_t)bgrid.nbricks * BT::row_ints());
                             BrickArgs<real> ta = brick_args();
                             ta.btab = btab.ptr;
+                            if (tsub > 1) {                          // the x-quarter boundaries of every brick's (species, tile cell) blocks
+                                bsub.ensure((size_t)bgrid.nbricks * BT::NTT + 4);
+                                ta.nsub = tsub; ta.bsub = bsub.ptr;
+                            }
                             hipLaunchKernelGGL((k_typed_tables<real, typename V::Shape, TT>), dim3(bgrid.per_xcd * NXCD), dim3(TT),
                                                BT::bytes(0), stream(), ta);
                             btab_valid = true;
                             auto kernel = k_typed_build<real, typename V::Shape, V::THREADS, V::GB, V::G>;
                             lds_build_bytes = typed_build_lds_bytes<typename V::Shape, V::THREADS>(tile_cap, own_cap, stride, V::GB, V::G);
                             allow_big_lds(kernel, lds_build_bytes);
-                            hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(), brick_args());
+                            BrickArgs<real> ba = brick_args();
+                            ba.nsub = ta.nsub; ba.bsub = ta.bsub;
+                            hipLaunchKernelGGL(kernel, dim3(bgrid.per_xcd * NXCD), dim3(V::THREADS), lds_build_bytes, stream(), ba);
                             return;
                         }
                     }

@@ -76,7 +76,7 @@ static inline size_t typed_force_lds_bytes(int own_cap) {
 template <class Shape, int THREADS>
 static inline size_t typed_build_lds_bytes(int tile_cap, int own_cap, int stride, int G, int GL = 4) {
     return (size_t)tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(own_cap) + (size_t)(THREADS / G) * typed_seg_cap(stride, GL) * 2 +
-           (size_t)(Shape::NOC + 1) * 9 * TNT * 8;
+           (((size_t)(Shape::NOC * 4 + 1) * 9 * TNT * 4 + 15) & ~(size_t)15);   // (row table: one packed word per (own cell, x quarter, species, row))
 }
 
 // tables of this block's brick; false when the block has nothing to do.  Contains block barriers.
@@ -121,14 +121,19 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
         wrap(gx, Mx, a.g.per[0], 0);
         wrap(gy, My, a.g.per[1], 2);
         wrap(gz, Mz, a.g.per[2], 4);
-        int gb = 0;
+        int gb = 0, packed = 0;
         if (valid) {
-            const size_t c = (size_t)(gx + Mx * (gy + My * gz)) * TNT + t;
+            const size_t c = ((size_t)(gx + Mx * (gy + My * gz)) * TNT + t) * a.tdig;
             gb = a.tstart[c];
-            my_cnt = a.tstart[c + 1] - gb;
+            my_cnt = a.tstart[c + a.tdig] - gb;
+            if (COMPUTE && a.bsub != nullptr) {          // x sub-bins: the three inner boundaries of the block (brick.hpp sub_below)
+                const int *fs = a.tstart + c;
+                packed = (fs[1] - gb) | ((fs[2] - gb) << 10) | ((fs[3] - gb) << 20);
+            }
         }
         T.gbeg[tid] = gb;
         if (t == 0) T.shift[tc] = sh;
+        if (COMPUTE && a.bsub != nullptr) a.bsub[(size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * NTT + tid] = packed;
     }
     // Decomposed runs: an own (species, cell) block that holds nothing but ghosts takes no part in the own-atom loops (as in
     // brick.hpp): bit 8 + species of the cell's shift word, set once the plain words are in place
@@ -183,7 +188,7 @@ __device__ __forceinline__ bool typed_setup(const BrickArgs<real> &a, const Type
 
 // own atom o -> (species, own cell) index q, tile slot, cell-order slot
 template <class Shape, int THREADS>
-__device__ __forceinline__ int typed_locate(const TypedTables<Shape, THREADS> &T, int o, int &ti, int &p) {
+__device__ __forceinline__ int typed_locate(const TypedTables<Shape, THREADS> &T, int o, int &ti, int &p, int *tc_out = nullptr) {
     constexpr int NOC = Shape::NOC, NTC = Shape::NTC;
     int q = 0;
 #pragma unroll
@@ -194,6 +199,7 @@ __device__ __forceinline__ int typed_locate(const TypedTables<Shape, THREADS> &T
     const int kk = o - T.own[q];
     ti = T.off[tc] + kk;
     p = T.gbeg[tc] + kk;
+    if (tc_out) *tc_out = tc;
     return q;
 }
 
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(THREADS) void k_typed_tables(BrickArgs<real> a) {
 // fields of the typed build can take is 16 G
 template <class Shape>
 __global__ void k_typed_span_max(BrickGrid bg, int Mx, int My, int Mz, int px, int py, int pz, const int *__restrict__ tstart,
-                                 int *__restrict__ out) {
+                                 int *__restrict__ out, int tdig = 1) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     int span3 = 0;
     if (b < bg.nbricks) {
@@ -258,8 +264,8 @@ __global__ void k_typed_span_max(BrickGrid bg, int Mx, int My, int Mz, int px, i
                     for (int t = 0; t < TNT; t++) {
                         int pop = 0;
                         if (valid) {
-                            const size_t c = (size_t)(gx + Mx * (gy + My * gz)) * TNT + t;
-                            pop = tstart[c + 1] - tstart[c];
+                            const size_t c = ((size_t)(gx + Mx * (gy + My * gz)) * TNT + t) * tdig;
+                            pop = tstart[c + tdig] - tstart[c];
                         }
                         span3 = max(span3, pop + p1[t] + p2[t]);
                         p2[t] = p1[t]; p1[t] = pop;
@@ -291,6 +297,18 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
     int bxi, byi, bzi, tile_n, n_own;
     if (!typed_setup<real, Shape, THREADS>(a, T, bxi, byi, bzi, tile_n, n_own)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    // x sub-bins (round 5; as brick.hpp's builds): a (cell, species) block is sorted by quarter along x, and an atom of quarter s
+    // takes the quarters >= s + K of the left cell of a candidate row, the middle cell and the quarters <= s - K of the right
+    // one -- 9 of 12 quarters where cells are just wider than r_list.  The boundaries of the tile's blocks (k_typed_tables
+    // wrote them) borrow the row buffers until the row table is in place.
+    constexpr int NTT = TNT * NTC;
+    const int NSUB = (a.nsub == 4 && a.bsub != nullptr) ? 4 : 1;
+    unsigned char *after = s_dyn + (size_t)a.tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(a.own_cap);
+    int *s_sub = reinterpret_cast<int *>(after);
+    if (NSUB > 1) {
+        const int *bs = a.bsub + (size_t)(bxi + a.bg.nb[0] * (byi + a.bg.nb[1] * bzi)) * NTT;
+        for (int i = tid; i < NTT; i += THREADS) s_sub[i] = bs[i];
+    }
 
     real org[3] = {0, 0, 0};
     if (sizeof(real) == 8) {
@@ -299,18 +317,23 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
         org[2] = a.g.lo[2] + (real)(bzi * Shape::BZ) * (a.g.len[2] / (real)a.g.M[2]);
     }
     __shared__ float s_relc[sizeof(real) == 4 ? Shape::TX + Shape::TY + Shape::TZ : 1];   // cell-relative records (brick.hpp rel_cell_const)
-    if (sizeof(real) == 4 && a.rel) {
-        rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
-        __syncthreads();
-    }
+    if (sizeof(real) == 4 && a.rel) rel_fill_consts<real, Shape>(a, bxi, byi, bzi, s_relc);
+    if (NSUB > 1 || (sizeof(real) == 4 && a.rel)) __syncthreads();
+    // quarter of the own atom at tile slot ti of typed tile cell tc
+    auto own_sub = [&](int tc, int ti) {
+        if (NSUB == 1) return 0;
+        const int kk = ti - T.off[tc], pk = s_sub[tc];
+        return (kk >= (pk & 1023) ? 1 : 0) + (kk >= ((pk >> 10) & 1023) ? 1 : 0) + (kk >= ((pk >> 20) & 1023) ? 1 : 0);
+    };
     int own_p[OWN_REGS], own_ti[OWN_REGS], own_key[OWN_REGS], own_q[OWN_REGS];
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
         own_p[k] = own_ti[k] = 0; own_key[k] = 0; own_q[k] = 0;
         if (o < n_own) {
-            own_q[k] = typed_locate(T, o, own_ti[k], own_p[k]);
-            own_key[k] = a.perm[own_p[k]];
+            int tc;
+            own_q[k] = typed_locate(T, o, own_ti[k], own_p[k], &tc);
+            own_key[k] = (a.perm[own_p[k]] < a.n_owned ? 1 : 0) | (own_sub(tc, own_ti[k]) << 1);
         }
     }
     typed_for_each_slot(T, [&](int s, int tc) {
@@ -334,25 +357,30 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
 #pragma unroll
     for (int k = 0; k < OWN_REGS; k++) {
         const int o = tid + k * THREADS;
-        if (o < n_own && EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(own_p[k], (own_q[k] << 20) | ((own_key[k] < a.n_owned ? 1 : 0) << 16) | own_ti[k]);
+        // (own_key: bit 0 = owned, bits 1-2 = x quarter)
+        if (o < n_own && EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(own_p[k], (own_q[k] << 20) | (own_key[k] << 16) | own_ti[k]);
     }
     for (int o = tid + OWN_REGS * THREADS; o < n_own; o += THREADS) {
-        int ti, p;
-        const int q = typed_locate(T, o, ti, p);
-        if (EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (q << 20) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
+        int ti, p, tc;
+        const int q = typed_locate(T, o, ti, p, &tc);
+        if (EMDEE_BOUND(BS_TYPED_OWN, o, a.own_cap)) T.oinfo[o] = make_int2(p, (q << 20) | (own_sub(tc, ti) << 17) | ((a.perm[p] < a.n_owned ? 1 : 0) << 16) | ti);
     }
-    // candidate rows per own cell: for each neighbour species the 9 tile rows of 3 cells around it, {first tile slot, slots};
-    // entry NOC is empty (atoms that own no row)
-    unsigned char *after = s_dyn + (size_t)a.tile_cap * 16 + TypedTables<Shape, THREADS>::bytes(a.own_cap);
-    int2 *rtab = reinterpret_cast<int2 *>(after + (size_t)NGROUPS * typed_seg_cap(a.stride, GL) * 2);
-    for (int i = tid; i < (NOC + 1) * NR2; i += THREADS) {
-        const int oc = i / NR2, tr = i % NR2, t = tr / NROWS, r = tr % NROWS;
-        int2 v = make_int2(0, 0);
-        if (oc < NOC) {
+    // candidate rows per own cell (and x quarter): for each neighbour species the 9 tile rows of 3 cells around it, packed as
+    // first tile slot | slots << 16 (a tile holds < 2^16 slots); the last entry is empty (atoms that own no row)
+    unsigned *rtab = reinterpret_cast<unsigned *>(after + (size_t)NGROUPS * typed_seg_cap(a.stride, GL) * 2);
+    for (int i = tid; i < (NOC * NSUB + 1) * NR2; i += THREADS) {
+        const int ocs = i / NR2, tr = i % NR2, t = tr / NROWS, r = tr % NROWS;
+        unsigned v = 0;
+        if (ocs < NOC * NSUB) {
+            const int oc = ocs / NSUB, sb = ocs - oc * NSUB;
             const int ox = oc % BX, oy = (oc / BX) % BY, oz = oc / (BX * BY);
             const int tcr = t * NTC + ox + TX * ((oy + r % 3) + TY * (oz + r / 3));   // cell x-1 of tile row (dy, dz) of species t
-            v.x = T.off[tcr];
-            v.y = T.off[tcr + 3] - v.x;
+            int first = T.off[tcr], last = T.off[tcr + 3];
+            if (NSUB > 1) {
+                first += sub_below(s_sub[tcr], sb + a.sub_k, T.off[tcr + 1] - T.off[tcr]);
+                last = T.off[tcr + 2] + sub_below(s_sub[tcr + 2], sb - a.sub_k + 1, T.off[tcr + 3] - T.off[tcr + 2]);
+            }
+            v = (unsigned)first | ((unsigned)(last - first) << 16);
         }
         rtab[i] = v;
     }
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
         const bool act = have && ((info.y >> 16) & 1) != 0;   // ghosts own no row
         const float4 qi = tile[ti];
         unsigned short *row = a.nbr + (size_t)p * a.stride;
-        const int2 *rt = rtab + (act ? oc : NOC) * NR2;
+        const unsigned *rt = rtab + (act ? oc * NSUB + ((info.y >> 17) & 3) : NOC * NSUB) * NR2;
         // wave-uniform trip counts of the 18 rows: per species, lane gl of every group holds the chunk length of row gl
         // (row 8 apart), three max steps combine the groups of the wavefront
         int trips_of[NR2];
@@ -389,8 +417,8 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
         };
 #pragma unroll
         for (int t = 0; t < TNT; t++) {
-            int cv = (int)((unsigned)(rt[t * NROWS + min(gl, NROWS - 1)].y + G - 1) / (unsigned)G);
-            int c8 = (int)((unsigned)(rt[t * NROWS + NROWS - 1].y + G - 1) / (unsigned)G);
+            int cv = (int)(((rt[t * NROWS + min(gl, NROWS - 1)] >> 16) + G - 1) / (unsigned)G);
+            int c8 = (int)(((rt[t * NROWS + NROWS - 1] >> 16) + G - 1) / (unsigned)G);
             cv = max(cv, __builtin_amdgcn_update_dpp(0, cv, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
             c8 = max(c8, __builtin_amdgcn_update_dpp(0, c8, 0x128, 0xf, 0xf, true));
             cv = rows_max(cv);
@@ -412,11 +440,11 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
         unsigned word[NWORDS];
 #pragma unroll
         for (int w = 0; w < NWORDS; w++) word[w] = 0;
-        int2 rv_next = rt[0];
+        unsigned rv_next = rt[0];
 #pragma unroll
         for (int tr = 0; tr < NR2; tr++) {
             const int t = tr / NROWS, r = tr % NROWS;
-            const int c0 = rv_next.x, span = rv_next.y;
+            const int c0 = (int)(rv_next & 0xffffu), span = (int)(rv_next >> 16);
             if (tr + 1 < NR2) rv_next = rt[tr + 1];
             const int lim = (int)((unsigned)(span - gl + G - 1) >> LOG2G);   // my candidates: slots cb + k G, k < lim (may be <= 0)
             const int cb = c0 + gl;
@@ -515,8 +543,8 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4
             for (int w = 0; w < WPT; w++) {
                 unsigned W = word[t * WPT + w];
                 // field A = row w of this species (bits 0..15), field B = the opposite row 8 - w (bits 16..31)
-                int cA = (rt[t * NROWS + w].x + gl) << a.idx_shift;
-                int cB = (w < 4) ? ((rt[t * NROWS + 8 - w].x + gl - 16 * G) << a.idx_shift) : 0;
+                int cA = ((int)(rt[t * NROWS + w] & 0xffffu) + gl) << a.idx_shift;
+                int cB = (w < 4) ? (((int)(rt[t * NROWS + 8 - w] & 0xffffu) + gl - 16 * G) << a.idx_shift) : 0;
                 asm volatile("" : "+v"(cA), "+v"(cB));
                 while (W) {
                     const int k = __ffs((int)W) - 1;

@@ -15,4 +15,4 @@ import json; d=json.loads(open('$O/bench_$name.json').read().strip().splitlines(
 print('mixture $name', round(d['value'],1), 'steps/s, step kernel', round(d['roofline']['avg_launch_ms'],4), 'ms, rebuild', round(rb[0]/max(rb[1],1),3), 'ms x', rb[1])"
   grep -i -m3 "plan" $O/bench_$name.err
 }
-run v9 A=1 && run v7 EMDEE_TYPED_BRICKS=7 && run v9_again A=1
+run v9 A=1 && run v9_nosub EMDEE_TYPED_SUBBINS=0 && run v7 EMDEE_TYPED_BRICKS=7 && run v9_again A=1
