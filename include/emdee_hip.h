@@ -18,6 +18,14 @@
  *   - Work is enqueued on the context's HIP stream; emdee_sync() and the calls that
  *     return host values are the only blocking calls.  One host thread per context,
  *     as in the reference (single-threaded host, async launches, src/nonbonded.jl:115-119).
+ *   - Streams.  A decomposed domain (emdee_dd_*) and the integrator it lends out (emdee_dd_engine)
+ *     run on streams the library owns.  The calls that copy an engine's state into caller arrays --
+ *     emdee_dd_get_state, emdee_md_get_state, emdee_md_nbr_list -- order themselves against the
+ *     caller's context stream inside the library: the engine's stream waits for what the caller's
+ *     stream had queued when the call was made (so a block the caller's allocator has just recycled is
+ *     not written early), and the caller's stream waits for the copies (so work queued on it after the
+ *     call sees them).  No device-wide synchronise, nothing for a binding to add.  Arrays handed IN
+ *     (emdee_dd_set_atoms, emdee_md_create, ...) are read on the context's stream, in order.
  *   - Arrays follow the reference: positions/forces/velocities are 3xN column-major
  *     (xyz interleaved, src/nonbonded.jl:52-61), energies/virials length N.
  *   - precision = bytes per real of the caller's arrays: EMDEE_F32 (the reference's
