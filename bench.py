@@ -610,7 +610,10 @@ def main():
                          # a rebuild = the read-back of the batch's request words that asked for it + those inside it (ONE, with
                          # the build's words, when it ran in the engines' own order)
                          "rebuilds_in_engine_order": phase1["rebuilds_in_engine_order"] - phase0["rebuilds_in_engine_order"],
-                         "readbacks_per_rebuild": 1.0 + (phase1["rebuild_readbacks"] - phase0["rebuild_readbacks"]) / max(phase1["rebuilds"] - phase0["rebuilds"], 1)})
+                         # (the counters are the PROCESS's: with several domains in one process every domain's build has its read-back,
+                         # so the figure is per local domain -- a rank of a real run is one process with one domain)
+                         "readbacks_per_rebuild": 1.0 + (phase1["rebuild_readbacks"] - phase0["rebuild_readbacks"]) /
+                                                  max((phase1["rebuilds"] - phase0["rebuilds"]) * max(len(local_engines), 1), 1)})
         ranks = mine
         if dist is not None:
             gathered = [None] * world
