@@ -117,3 +117,15 @@ def test_target_box_leg_cannot_lose_the_headline_line():
     assert d["config"]["decomposition"].startswith("native")
     assert "timed out" in d["target_box"].get("error", ""), d["target_box"]
     assert d["value"] > 0 and d["energy_per_atom"]["kinetic"] > 0.5
+
+
+def test_worked_examples_run(tmp_path):
+    """examples/lj_fluid.py and examples/lj_fluid_decomposed.py (README.md "worked examples") end to end on small boxes: NVT -> NVE,
+    XYZ frame, checkpoint restart, the operator on caller arrays; the same fluid cut into four in-process domains."""
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    for script, args in (("lj_fluid.py", ["10"]), ("lj_fluid_decomposed.py", ["4", "12"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, script + ": " + r.stdout[-600:] + r.stderr[-1200:]
+        assert "relative energy change" in r.stdout or "energy" in r.stdout, r.stdout[-600:]

@@ -386,6 +386,26 @@ def test_two_species_boxes_take_the_typed_kernels(emdee, oracle, dev, capfd, mon
     dx = a["x12"] - b["x12"]
     assert np.abs(dx - L * np.rint(dx / L)).max() < (1e-10 if dtype == np.float64 else 2e-4)
     if dtype == np.float64:
+        # the A/B baselines of round 5 stay honest: the (cell, species) sort without x quarters, and -- long rows -- the 4 x 2 x 2
+        # bricks in 1024-thread workgroups, give the same rows and the same forces
+        monkeypatch.delenv("EMDEE_NO_TYPED", raising=False)
+        monkeypatch.setenv("EMDEE_TYPED_SUBBINS", "0")
+        monkeypatch.setenv("EMDEE_TYPED_BRICKS", "7")
+        monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
+        capfd.readouterr()
+        tiles = E.nonbonded_computation_tiles(N)
+        f = torch.zeros((N, 3), dtype=tdt, device=dev)
+        E.compute_nonbonded_(f, None, None, E.cu(x, dev), L, tiles, model, E.cu(atoms, dev), 1)
+        torch.cuda.synchronize()
+        err = capfd.readouterr().err
+        assert "typed kernels on" in err and "variant 9" not in err, err[-400:]
+        rows7 = _rows(*tiles.neighbor_lists())
+        for i in range(N):
+            assert np.array_equal(rows7[i], a["rows"][i]), "row %d: the baseline typed build disagrees" % i
+        assert np.abs(f.cpu().numpy() - a["f"]).max() <= tol * np.abs(a["f"]).max()
+        for k in ("EMDEE_TYPED_SUBBINS", "EMDEE_TYPED_BRICKS", "EMDEE_DEBUG_PLAN"):
+            monkeypatch.delenv(k, raising=False)
+    if dtype == np.float64:
         f0, e0, w0 = oracle.nonbonded_cells(pos, L, oracle.model(rc, rs), atoms)
         assert np.abs(a["f"] - f0).max() <= 1e-9 * np.abs(f0).max()
         assert np.abs(a["e"] - e0).max() <= 1e-9 * np.abs(e0).max() and np.abs(a["w"] - w0).max() <= 1e-9 * np.abs(w0).max()
