@@ -586,3 +586,52 @@ def test_exclusions_and_scaled_14_pairs(emdee, oracle, dev, lj_sample, monkeypat
     half.step_(40, 0.002)
     eph, ekh, _ = half.totals()
     assert abs((eph + ekh) - (ep0 + ek0)) > 2.5 * abs((ep1 + ek1) - (ep0 + ek0))          # ... and it shrinks with dt^2
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_exclusions_on_a_single_species_box(emdee, oracle, dev, dtype):
+    """The kernel class of the headline box -- one LJAtom value: coordinate-plane tiles, list entries stored as byte offsets into
+    the planes -- with an exclusion table: a 32,000-atom jittered lattice (tiled kernels, x sub-bins), every atom's lattice
+    neighbour pairs 2k / 2k + 1 excluded.  Operator outputs and the integrator's forces against the oracle's full sum minus
+    the named pairs; Float32 through the integrator's brick-relative tiles (EMDEE_F32_FAST) so that the filtered rows are
+    the ones the fp32 MD kernels walk.  The rows hold every listed neighbour but the named ones."""
+    E = emdee
+    x0, L = E.synthetic.fcc_positions(20)
+    N = x0.shape[0]
+    rc, rs = 2.5, 2.0
+    atoms = E.lennard_jones_atoms(1.0, 1.0, N)
+    ndt = np.float64 if dtype == "f64" else np.float32
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    x = x0.astype(ndt)
+    x64 = x.astype(np.float64)
+    excl = np.arange(N).reshape(-1, 2)                                   # consecutive atoms of an fcc cell: first neighbours
+    om = oracle.model(rc, rs)
+    f0, e0, w0 = oracle.nonbonded_cells(x64, L, om, atoms)
+    fx, ex, wx = _pair_terms(oracle, x64, L, om, atoms, excl)
+    assert np.abs(fx).max() > 1e-2 * np.abs(f0).max()
+    want_f, want_e = f0 - fx, e0 - ex
+    tol = 1e-6 if dtype == "f64" else 2e-4
+    md = E.VelocityVerlet(E.cu(x, dev), E.cu(np.zeros_like(x), dev), L, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), skin=0.3)
+    md.set_exclusions_(excl)
+    st = md.state(energies=True)
+    assert np.abs(st["forces"].cpu().numpy() - want_f).max() <= tol * np.abs(want_f).max()
+    assert np.abs(st["energies"].cpu().numpy() - want_e).max() <= tol * np.abs(want_e).max()
+    rows = _rows(*md.neighbor_lists())
+    full = _oracle_rows(oracle, x64, L, rc + 0.3)
+    partner = np.arange(N) ^ 1
+    bad = 0
+    for i in range(N):
+        expect = full[i][full[i] != partner[i]]
+        if not np.array_equal(rows[i], expect):
+            bad += 1
+            # (Float32: a pair within one rounding of r_list may be listed or not; the named pair must be gone either way)
+            assert dtype == "f32" and partner[i] not in rows[i] and len(np.setxor1d(rows[i], expect)) <= 2, i
+    assert bad <= (0 if dtype == "f64" else 16)
+    # a few steps with rebuilds: the re-sorted state is filtered again (the pair would otherwise come back into the rows)
+    md2 = E.VelocityVerlet(E.cu(x, dev), E.cu((0.8 * E.synthetic.velocities(N)).astype(ndt), dev), L, E.LennardJonesModel(rc, rs), E.cu(atoms, dev), skin=0.3)
+    md2.set_exclusions_(excl)
+    md2.step_(40, 0.004)
+    assert md2.nbr_stats()["builds"] >= 3
+    rows2 = _rows(*md2.neighbor_lists())
+    assert all(partner[i] not in rows2[i] for i in range(0, N, 7))
+    md.close(); md2.close()
