@@ -603,7 +603,31 @@ def test_long_rows_binary_mixture_rc35(emdee, oracle, dev):
     assert np.abs(dx - L * np.rint(dx / L)).max() < 1e-9
 
 
-def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev, capfd, monkeypatch):
+def _sampled_atoms_against_the_oracle(oracle, xd, L, rc, rs, orc_atoms, forces, energies, sample, tol=1e-9):
+    """Boxes the oracle cannot walk in seconds: for every sampled atom all atoms within r_c by brute force (one minimum-image
+    distance pass over ALL positions, torch on the device -- a witness that shares nothing with the cell grid, the sort or the
+    list), then the oracle's pair function (src/lennard_jones.jl:25-42 restated) sums its force (src/nonbonded.jl:139) and
+    half-energies (:142-145).  The HIP path can only agree if the atom's row is complete."""
+    om = oracle.model(rc, rs)
+    fmax = forces.abs().max().item()
+    for i in sample:
+        d = xd[i] - xd                                        # x_i - x_j, minimum image (src/nonbonded.jl:40)
+        d -= L * torch.round(d / L)
+        r2 = (d * d).sum(dim=1)
+        near = torch.nonzero((r2 < rc * rc) & (r2 > 0.0)).flatten()
+        dn, rn, jn = d[near].cpu().numpy(), r2[near].cpu().numpy(), near.cpu().numpy()
+        del d, r2
+        f_i, e_i = np.zeros(3), 0.0
+        for k in range(dn.shape[0]):
+            Ek, Wk = oracle.interaction(float(rn[k]), om, orc_atoms[i], orc_atoms[jn[k]], mode=oracle.CUTOFF)
+            f_i += Wk / rn[k] * dn[k]
+            e_i += 0.5 * Ek
+        assert np.abs(forces[i].cpu().numpy() - f_i).max() <= tol * fmax, i
+        assert abs(energies[i].item() - e_i) <= tol * max(abs(e_i), 1e-3), i
+    return fmax
+
+
+def test_ten_million_atom_binary_mixture_rc35_properties(emdee, oracle, dev, capfd, monkeypatch):
     """BASELINE configs[4] at the size it is quoted on: 10,061,824 atoms, two species (Lorentz-Berthelot through the LJAtom
     encoding, src/lennard_jones.jl:13-18,29-30), rc = 3.5 sigma -- stepped by the TYPED two-species kernels (csrc/typed.hpp:
     rows of two segments, 184 entries, coordinate-plane tiles; asserted below from the plan the library prints).  No CPU
@@ -621,9 +645,16 @@ def test_ten_million_atom_binary_mixture_rc35_properties(emdee, dev, capfd, monk
     atoms = E.lennard_jones_atoms(eps, sigma)
     monkeypatch.setenv("EMDEE_DEBUG_PLAN", "1")
     capfd.readouterr()
-    md = E.VelocityVerlet(E.cu(pos, dev), E.cu(vel, dev), L, E.LennardJonesModel(3.5, 3.0), E.cu(atoms, dev), skin=0.3)
+    xd = E.cu(pos, dev)
+    md = E.VelocityVerlet(xd, E.cu(vel, dev), L, E.LennardJonesModel(3.5, 3.0), E.cu(atoms, dev), skin=0.3)
     torch.cuda.synchronize()
     assert "typed kernels on" in capfd.readouterr().err               # the kernels that step THIS box are the typed ones
+    # (round 5) 38 sampled atoms of both species -- the six with extreme coordinates among them -- against the oracle's pair function
+    sample = [int(pos[:, d].argmin()) for d in range(3)] + [int(pos[:, d].argmax()) for d in range(3)]
+    sample += [int(i) for i in np.random.default_rng(12).integers(0, N, size=32)]
+    st0 = md.state(positions=False, velocities=False, energies=True)
+    _sampled_atoms_against_the_oracle(oracle, xd, L, 3.5, 3.0, oracle.lj_atoms(eps, sigma), st0["forces"], st0["energies"], sample)
+    del st0, xd
     del pos, vel
     ep0, ek0, _ = md.totals()
     pairs = md.count_pairs()
@@ -715,24 +746,10 @@ def test_target_size_hundred_million_atoms(emdee, oracle, dev):
     del pos, vel
     ep0, ek0, _ = md.totals()
     st = md.state(positions=False, energies=True)
-    om = oracle.model(rc, rs)
-    one = oracle.lj_atoms(np.ones(1), np.ones(1))[0]
-    fmax = st["forces"].abs().max().item()
-    for i in sample:
-        d = xd[i] - xd                                        # x_i - x_j, minimum image (src/nonbonded.jl:40)
-        d -= L * torch.round(d / L)
-        r2 = (d * d).sum(dim=1)
-        near = torch.nonzero((r2 < rc * rc) & (r2 > 0.0)).flatten()
-        assert 30 <= near.numel() <= 80                        # (~52 expected at rho* = 0.8)
-        dn, rn = d[near].cpu().numpy(), r2[near].cpu().numpy()
-        del d, r2
-        f_i, e_i = np.zeros(3), 0.0
-        for k in range(dn.shape[0]):
-            Ek, Wk = oracle.interaction(float(rn[k]), om, one, one, mode=oracle.CUTOFF)
-            f_i += Wk / rn[k] * dn[k]                          # src/nonbonded.jl:139
-            e_i += 0.5 * Ek                                    # src/nonbonded.jl:142-145
-        assert np.abs(st["forces"][i].cpu().numpy() - f_i).max() <= 1e-9 * fmax, i
-        assert abs(st["energies"][i].item() - e_i) <= 1e-9 * abs(e_i), i
+    class _One:                                                # (10^8 identical LJAtom records: one will do)
+        rec = oracle.lj_atoms(np.ones(1), np.ones(1))[0]
+        def __getitem__(self, k): return self.rec
+    fmax = _sampled_atoms_against_the_oracle(oracle, xd, L, rc, rs, _One(), st["forces"], st["energies"], sample)
     p0 = st["velocities"].sum(dim=0)
     assert st["forces"].sum(dim=0).abs().max().item() < 1e-6 * fmax * np.sqrt(N)
     del st, xd
