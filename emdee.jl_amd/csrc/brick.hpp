@@ -174,12 +174,12 @@ struct BrickArgs {
 // ---- cell-relative records: tile coordinates (kernels.hpp RelGrid) ---------------------------------
 // the integer (as a float: < 2^24) that takes round(record x 2^19) of an atom of the tile cell at offset t (-1 .. B) from the
 // brick's first own cell b, along dimension d, to its brick-relative tile coordinate in grid points
-template <typename real>
-__device__ __forceinline__ float rel_cell_const(const BrickArgs<real> &a, int d, int b, int t) {
-    const int M = a.g.M[d];
+// (M, lo, cw of ONE dimension are passed as values: indexing the kernel-argument struct with a run-time dimension makes the compiler
+// keep a copy of the whole struct in scratch memory -- the fp32 two-species kernel ran at 5.0 instead of 2.2 ms for that, found in round 5)
+__device__ __forceinline__ float rel_cell_const(int M, double lo, double cw, int b, int t) {
     int cg = b + t, img = 0;                                 // the cell of the box this tile cell is an image of
     if (cg < 0) { cg += M; img = -1; } else if (cg >= M) { cg -= M; img = 1; }
-    auto oq = [&](int c) { return rint((a.rlo[d] + (double)c * a.rcw[d]) * 524288.0); };
+    auto oq = [&](int c) { return rint((lo + (double)c * cw) * 524288.0); };
     return (float)(oq(cg) + (double)img * oq(M) - (double)img * oq(0) - oq(b));
 }
 // ... for the TX + TY + TZ tile-cell offsets of a brick, into LDS (56 bytes): call with every thread, then a barrier
@@ -187,9 +187,9 @@ template <typename real, class Shape>
 __device__ __forceinline__ void rel_fill_consts(const BrickArgs<real> &a, int bxi, int byi, int bzi, float *relc) {
     constexpr int TX = Shape::TX, TY = Shape::TY, TZ = Shape::TZ;
     const int t = threadIdx.x;
-    if (t < TX) relc[t] = rel_cell_const(a, 0, bxi * Shape::BX, t - 1);
-    else if (t < TX + TY) relc[t] = rel_cell_const(a, 1, byi * Shape::BY, t - TX - 1);
-    else if (t < TX + TY + TZ) relc[t] = rel_cell_const(a, 2, bzi * Shape::BZ, t - TX - TY - 1);
+    if (t < TX) relc[t] = rel_cell_const(a.g.M[0], a.rlo[0], a.rcw[0], bxi * Shape::BX, t - 1);
+    else if (t < TX + TY) relc[t] = rel_cell_const(a.g.M[1], a.rlo[1], a.rcw[1], byi * Shape::BY, t - TX - 1);
+    else if (t < TX + TY + TZ) relc[t] = rel_cell_const(a.g.M[2], a.rlo[2], a.rcw[2], bzi * Shape::BZ, t - TX - TY - 1);
 }
 __device__ __forceinline__ float rel_tile(float v, float c) { return (rintf(v * REL_FX) + c) * REL_IFX; }
 __device__ __forceinline__ double rel_tile(double v, float) { return v; }   // (fp64 states are never cell-relative)

@@ -113,6 +113,41 @@ __device__ __forceinline__ real lj_force_over_r2(real r2, real inv_r2, const LJM
     return (d * g6) * inv_r2 + em * q;
 }
 
+// ---- two-species (typed) MD kernels, force-only launches: 4 eps_ij of the segment folded into the switch constants ------
+// lj_force_over_r2 with a = s^-6 instead of 4 eps s^-6: the factor moves into 6 g's Horner constants and into 60 idl2, which a
+// lane of the typed kernels holds per neighbour species anyway (csrc/typed.hpp).  One multiply per pair step less; different
+// from lj_force_over_r2 only in rounding.
+template <typename real>
+struct LJSeg {
+    real sig2;                 // sigma_ij^2
+    real p0, p3, p4, p5;       // 4 eps_ij (6, -60, 90, -36)
+    real c60;                  // 4 eps_ij 60 idl2
+};
+template <typename real>
+__host__ __device__ inline LJSeg<real> make_seg(const LJModel<real> &m, real sig2, real e4) {
+    LJSeg<real> c;
+    c.sig2 = sig2;
+    c.p0 = m.k6 * e4; c.p3 = m.h3 * e4; c.p4 = m.h4 * e4; c.p5 = m.h5 * e4;
+    c.c60 = m.c60 * e4;
+    return c;
+}
+template <typename real>
+__device__ __forceinline__ real lj_force_over_r2_seg(real r2, real inv_r2, const LJModel<real> &m, const LJSeg<real> &c) {
+    const real s2 = c.sig2 * inv_r2;
+    const real s6 = s2 * s2 * s2;                                      // a / 4 eps
+    const real b = s6 * s6;                                            // b / 4 eps
+    const real d = (real)2 * b - s6;                                   // W / (6 . 4 eps)
+    const real em = b - s6;                                            // E / 4 eps
+    const real x = fma_clamp01(r2, m.idl2, m.nx0);
+    const real x2 = x * x;
+    real t = c.p5 * x + c.p4;
+    t = t * x + c.p3;
+    const real g6 = (x2 * x) * t + c.p0;                               // 4 eps 6 g
+    const real y = x - x2;
+    const real q = (c.c60 * y) * y;                                    // 4 eps (-r g') / r2
+    return (d * g6) * inv_r2 + em * q;
+}
+
 // ---- single-species MD kernels: the same function with everything constant folded into the launch constants ------
 // All atoms carry one LJAtom, so sigma and 4 eps are launch constants.  The kernel works in coordinates scaled by
 // 1/sigma (done once per record while the tile is staged): s^-2 is then 1/r'^2 itself; 4 eps is folded into the

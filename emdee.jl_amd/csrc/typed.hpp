@@ -71,7 +71,7 @@ struct TypedTables {
 
 template <typename real, class Shape, int THREADS>
 static inline size_t typed_force_lds_bytes(int own_cap) {
-    return (((size_t)3 * typed_pitch<real, Shape, THREADS>() * sizeof(real) + 15) & ~(size_t)15) + TypedTables<Shape, THREADS>::bytes(own_cap) + 64;
+    return (((size_t)3 * typed_pitch<real, Shape, THREADS>() * sizeof(real) + 15) & ~(size_t)15) + TypedTables<Shape, THREADS>::bytes(own_cap) + 256;   // (+ the four pair-constant records)
 }
 template <class Shape, int THREADS>
 static inline size_t typed_build_lds_bytes(int tile_cap, int own_cap, int stride, int G, int GL = 4) {
@@ -284,7 +284,7 @@ __global__ void k_typed_span_max(BrickGrid bg, int Mx, int My, int Mz, int px, i
 // per species.  Row of atom p: entries [0, n0) = neighbours of species 0, [S1, S1 + n1) = neighbours of species 1 with
 // S1 = n0 rounded up to a whole block of 8 GL entries; cnt[p] = n0 | n1 << 16.
 template <typename real, class Shape, int THREADS, int G, int GL>
-__global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 6 : 4)) void k_typed_build(BrickArgs<real> a) {   // (2 x 2 x 2 bricks: two 512-thread workgroups per CU = 4 waves per SIMD)
+__global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 5 : 4)) void k_typed_build(BrickArgs<real> a) {   // (2 x 2 x 2 bricks: two 512-thread workgroups per CU = 4 waves per SIMD; short-row boxes, EMDEE_TYPED_ALL: 5 -- at 6 the build spilled 12 registers per lane once it took the x quarters)
     constexpr int BX = Shape::BX, BY = Shape::BY, TX = Shape::TX, TY = Shape::TY, NTC = Shape::NTC, NOC = Shape::NOC;
     constexpr int NGROUPS = (THREADS / WAVE) * (WAVE / G);
     static_assert(G == 8, "typed build: 8 lanes per atom");
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(Br
     constexpr size_t TILE_BYTES = ((size_t)3 * PITCH * sizeof(real) + 15) & ~(size_t)15;
     TypedTables<Shape, THREADS> T;
     T.carve(s_dyn + TILE_BYTES);
-    struct PairC { real sig2, e4; };
+    struct PairC { real sig2, e4; LJSeg<real> seg; };               // (seg: the force-only launches' folded constants, lj_pair.hpp)
     PairC *ptab = reinterpret_cast<PairC *>(s_dyn + TILE_BYTES + TypedTables<Shape, THREADS>::bytes(a.own_cap));   // [species_i * 2 + species_j]
     if (MODE == BRICK_STEP && a.guard != nullptr && *a.guard != 0) {
         if (threadIdx.x == 0) *a.trigger = 1;                               // a step queued behind a rebuild request: no trace
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(Br
         const real big = sizeof(real) == 8 ? (real)1e30 : (real)1e18;
         plane[0] = big; plane[PITCH] = big; plane[2 * PITCH] = big;
     }
-    if (tid < TNT * TNT) { PairC c; c.sig2 = a.tsig2[tid]; c.e4 = a.te4[tid]; ptab[tid] = c; }
+    if (tid < TNT * TNT) { PairC c; c.sig2 = a.tsig2[tid]; c.e4 = a.te4[tid]; c.seg = make_seg(a.model, c.sig2, c.e4); ptab[tid] = c; }
     // per own atom: {cell-order slot | species << 30, tile slot} and the two segment lengths n0 | n1 << 16
     T.carve_counts(a.own_cap);
 #pragma unroll
@@ -669,7 +669,15 @@ __global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(Br
     __syncthreads();
 
     LJModel<real> mdl = a.model;
-    if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.nx0), "+v"(mdl.idl2), "+v"(mdl.h4), "+v"(mdl.h3), "+v"(mdl.k6));
+    // fp64: 4 eps_ij folded into the segment's switch constants (lj_pair.hpp LJSeg: 3.077 -> 3.042 ms per launch, same box twice;
+    // fp32 loses with it, 2.12 -> 2.21 ms: ten more live registers per lane; profiles/r05/call_v.sh)
+#ifdef EMDEE_TYPED_NO_FOLD
+    constexpr bool FOLD = false;
+#else
+    constexpr bool FOLD = sizeof(real) == 8;
+#endif
+    if (BITMASK == EMDEE_FORCES && FOLD) asm volatile("" : "+v"(mdl.nx0), "+v"(mdl.idl2));    // (the Horner constants are the segment's)
+    else if (BITMASK == EMDEE_FORCES) asm volatile("" : "+v"(mdl.nx0), "+v"(mdl.idl2), "+v"(mdl.h4), "+v"(mdl.h3), "+v"(mdl.k6));
     else asm volatile("" : "+v"(mdl.x0), "+v"(mdl.k3));
 
     const int gl = lane & (G - 1);
@@ -731,7 +739,8 @@ __global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(Br
                 } else if (r2 < a.model.rc2) {                // strict test (Q2)
                     const real inv_r2 = fast_rcp(r2);
                     if (BITMASK == EMDEE_FORCES) {
-                        const real wr2 = lj_force_over_r2(r2, inv_r2, mdl, c.sig2, c.e4);
+                        // (A/B: profiles/build_variant.sh nofold -DEMDEE_TYPED_NO_FOLD=1)
+                        const real wr2 = FOLD ? lj_force_over_r2_seg(r2, inv_r2, mdl, c.seg) : lj_force_over_r2(r2, inv_r2, mdl, c.sig2, c.e4);
                         fx += wr2 * dx; fy += wr2 * dy; fz += wr2 * dz;
                     } else {
                         real E, W;
