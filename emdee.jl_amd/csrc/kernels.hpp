@@ -325,9 +325,11 @@ static __global__ void k_cell_scatter_keyed(int n, const int *__restrict__ cell_
 }
 // (n_dev, optional: the number of items that were scattered, as a device word -- a re-sort with struck-out items launches over
 // the upper bound; equal keys -- only the low words of two 64-bit tags can collide -- are ranked by the item index)
+// (ties: keys that are caller ids or slots of the previous order are unique and the loop reads the keys alone, as in rounds 1-4
+// -- 0.06 ms per rebuild at 10^7 atoms against 0.095 with the tie-break)
 static __global__ void k_cell_rankfix_keyed(int n, const int *__restrict__ cell_of, const int *__restrict__ start,
                                             const int2 *__restrict__ tmp, int *__restrict__ order,
-                                            const int *__restrict__ n_dev = nullptr) {
+                                            const int *__restrict__ n_dev = nullptr, int ties = 1) {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) n = min(n, *n_dev);
     if (q >= n) return;
@@ -335,9 +337,13 @@ static __global__ void k_cell_rankfix_keyed(int n, const int *__restrict__ cell_
     const int c = cell_of[me.x];
     const int s = start[c], e = start[c + 1];
     int rank = 0;
-    for (int r = s; r < e; r++) {
-        const int2 o = tmp[r];
-        rank += (o.y < me.y || (o.y == me.y && o.x < me.x)) ? 1 : 0;
+    if (ties) {
+        for (int r = s; r < e; r++) {
+            const int2 o = tmp[r];
+            rank += (o.y < me.y || (o.y == me.y && o.x < me.x)) ? 1 : 0;
+        }
+    } else {
+        for (int r = s; r < e; r++) rank += (tmp[r].y < me.y) ? 1 : 0;
     }
     order[s + rank] = me.x;
 }

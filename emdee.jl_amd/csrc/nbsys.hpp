@@ -376,7 +376,7 @@ struct NbSystem {
         hipLaunchKernelGGL(k_cell_scatter_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
                            fill.ptr, key, tmp2.ptr, tagkey);
         hipLaunchKernelGGL(k_cell_rankfix_keyed, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, cell_of.ptr, count.ptr,
-                           tmp2.ptr, order.ptr, keep ? count.ptr + nbins : nullptr);
+                           tmp2.ptr, order.ptr, keep ? count.ptr + nbins : nullptr, tagkey != nullptr ? 1 : 0);
         // (the first slot of every cell, cstart[], is written by the gather kernel that follows)
     }
     // K: how many quarters of a neighbour cell lie beyond r_list whatever the atom's position in its own quarter: the
