@@ -1535,7 +1535,10 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
 #endif
             // (EMDEE_PREFETCH_XJ, on: the coordinates of entry t + 1 are requested before the arithmetic of entry t, as in the typed
             // kernels -- round 5, same-box A/B of the build: fused launch 1.290 -> 1.280 ms, 600 -> 603.6 steps/s; =0 is the A/B baseline)
-            constexpr bool AHEAD = SOA && EMDEE_PREFETCH_XJ != 0;
+            // Force-only launches (the integrator's): with energies or virials as well the six registers of the read-ahead take the fp64
+            // kernel from 76 to 82 VGPRs and a third workgroup off the CU -- the operator's F+E+W call went 1.49 -> 1.53 ms for it
+            // (found by running round 4's tree beside this one, profiles/r05/r04_vs_r05_same_box.txt)
+            constexpr bool AHEAD = SOA && EMDEE_PREFETCH_XJ != 0 && BITMASK == EMDEE_FORCES;
             real xn = 0, yn = 0, zn = 0;
             if (AHEAD) {
                 const unsigned char *pn = plane_b + pick16(q, 0);
