@@ -458,14 +458,15 @@ __device__ __forceinline__ void brick_for_each_slot(const BrickTables<Shape, THR
     const int worker = threadIdx.x / STAGE_LANES, l = threadIdx.x % STAGE_LANES;
     for (int row = worker; row < NROWS; row += NW) {
         const int c0 = row * TX;
+        const int ty = row % Shape::TY, tz = row / Shape::TY;      // (per row, not per slot: the cell-relative staging indexes by them)
         int edge[TX + 1];
 #pragma unroll
         for (int c = 0; c <= TX; c++) edge[c] = T.off[c0 + c];
         for (int s = edge[0] + l; s < edge[TX]; s += STAGE_LANES) {
-            int tc = c0;
+            int tx = 0;
 #pragma unroll
-            for (int c = 1; c < TX; c++) tc += (edge[c] <= s) ? 1 : 0;
-            f(s, tc);
+            for (int c = 1; c < TX; c++) tx += (edge[c] <= s) ? 1 : 0;
+            f(s, c0 + tx, tx, ty, tz);
         }
     }
 }
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             own_key[k] = a.perm[own_p[k]];
         }
     }
-    brick_for_each_slot(T, [&](int s, int tc) {
+    brick_for_each_slot(T, [&](int s, int tc, int tx, int ty, int tz) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         const Rec<real> r = a.rec[gp];
@@ -584,9 +585,9 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 768 ? 6 : 4)) void k_brick_bui
             q.y = (float)(((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]) * ks);
             q.z = (float)(((r.z + (real)(((sh >> 4) & 3) - 1) * a.g.len[2]) - org[2]) * ks);
         } else if (sizeof(real) == 4 && a.rel) {              // cell-relative records: the tile coordinates the force kernels see, to the bit
-            q.x = (float)rel_tile(r.x, s_relc[tc % TX]);
-            q.y = (float)rel_tile(r.y, s_relc[TX + (tc / TX) % TY]);
-            q.z = (float)rel_tile(r.z, s_relc[TX + TY + tc / (TX * TY)]);
+            q.x = (float)rel_tile(r.x, s_relc[tx]);
+            q.y = (float)rel_tile(r.y, s_relc[TX + ty]);
+            q.z = (float)rel_tile(r.z, s_relc[TX + TY + tz]);
         } else {
             q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
             q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
@@ -1375,7 +1376,7 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
         org[1] = (double)a.g.lo[1] + (double)(byi * Shape::BY) * ((double)a.g.len[1] / (double)a.g.M[1]);
         org[2] = (double)a.g.lo[2] + (double)(bzi * Shape::BZ) * ((double)a.g.len[2] / (double)a.g.M[2]);
     }
-    brick_for_each_slot(T, [&](int s, int tc) {
+    brick_for_each_slot(T, [&](int s, int tc, int tx, int ty, int tz) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         Rec<real> r = a.rec[gp];
@@ -1383,8 +1384,8 @@ __global__ __launch_bounds__(THREADS) void k_brick(BrickArgs<real> a) {
             const size_t i = (size_t)a.perm[gp];
             r.x = a.user_pos[3 * i] / a.g.len[0]; r.y = a.user_pos[3 * i + 1] / a.g.len[1]; r.z = a.user_pos[3 * i + 2] / a.g.len[2];
         } else if (REL && a.rel) {                            // cell-relative records (BrickArgs::rel): fixed-point tile coordinates
-            r.x = (real)rel_tile(r.x, s_relc[tc % Shape::TX]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + (tc / Shape::TX) % Shape::TY]);
-            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + tc / (Shape::TX * Shape::TY)]);
+            r.x = (real)rel_tile(r.x, s_relc[tx]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + ty]);
+            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + tz]);
         } else if (REL) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);

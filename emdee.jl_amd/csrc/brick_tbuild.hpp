@@ -88,7 +88,7 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 ? EMDEE_TB_WAVES : 4)) voi
             ownflag[o] = a.perm[p] < a.n_owned ? 1 : 0;
         }
     }
-    brick_for_each_slot(T, [&](int s, int tc) {
+    brick_for_each_slot(T, [&](int s, int tc, int, int, int) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc];
         const Rec<real> r = a.rec[gp];

@@ -210,14 +210,15 @@ __device__ __forceinline__ void typed_for_each_slot(const TypedTables<Shape, THR
     const int worker = threadIdx.x / STAGE_LANES, l = threadIdx.x % STAGE_LANES;
     for (int row = worker; row < NROWS; row += NW) {
         const int c0 = (row / NYZ) * Shape::NTC + (row % NYZ) * TX;
+        const int ty = (row % NYZ) % Shape::TY, tz = (row % NYZ) / Shape::TY;   // (per row: the cell-relative staging indexes by them)
         int edge[TX + 1];
 #pragma unroll
         for (int c = 0; c <= TX; c++) edge[c] = T.off[c0 + c];
         for (int s = edge[0] + l; s < edge[TX]; s += STAGE_LANES) {
-            int tc = c0;
+            int tx = 0;
 #pragma unroll
-            for (int c = 1; c < TX; c++) tc += (edge[c] <= s) ? 1 : 0;
-            f(s, tc);
+            for (int c = 1; c < TX; c++) tx += (edge[c] <= s) ? 1 : 0;
+            f(s, c0 + tx, tx, ty, tz);
         }
     }
 }
@@ -336,16 +337,15 @@ __global__ __launch_bounds__(THREADS, (THREADS <= 512 && Shape::NOC != 8 ? 5 : 4
             own_key[k] = (a.perm[own_p[k]] < a.n_owned ? 1 : 0) | (own_sub(tc, own_ti[k]) << 1);
         }
     }
-    typed_for_each_slot(T, [&](int s, int tc) {
+    typed_for_each_slot(T, [&](int s, int tc, int tx, int ty, int tz) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc % NTC];
         const Rec<real> r = a.rec[gp];
         float4 q;
         if (sizeof(real) == 4 && a.rel) {                     // cell-relative records (brick.hpp rel_tile)
-            const int uc = tc % NTC;
-            q.x = (float)rel_tile(r.x, s_relc[uc % TX]);
-            q.y = (float)rel_tile(r.y, s_relc[TX + (uc / TX) % TY]);
-            q.z = (float)rel_tile(r.z, s_relc[TX + TY + uc / (TX * TY)]);
+            q.x = (float)rel_tile(r.x, s_relc[tx]);
+            q.y = (float)rel_tile(r.y, s_relc[TX + ty]);
+            q.z = (float)rel_tile(r.z, s_relc[TX + TY + tz]);
         } else {
             q.x = (float)((r.x + (real)((sh & 3) - 1) * a.g.len[0]) - org[0]);
             q.y = (float)((r.y + (real)(((sh >> 2) & 3) - 1) * a.g.len[1]) - org[1]);
@@ -628,14 +628,13 @@ __global__ __launch_bounds__(THREADS, (Shape::NOC == 8 ? 4 : 1)) void k_typed(Br
         org[1] = (double)a.g.lo[1] + (double)(byi * Shape::BY) * ((double)a.g.len[1] / (double)a.g.M[1]);
         org[2] = (double)a.g.lo[2] + (double)(bzi * Shape::BZ) * ((double)a.g.len[2] / (double)a.g.M[2]);
     }
-    typed_for_each_slot(T, [&](int s, int tc) {
+    typed_for_each_slot(T, [&](int s, int tc, int tx, int ty, int tz) {
         const int gp = T.gbeg[tc] + (s - T.off[tc]);
         const int sh = T.shift[tc % NTC];
         Rec<real> r = a.rec[gp];
         if (REL && a.rel) {                                   // cell-relative records: fixed-point tile coordinates (brick.hpp k_brick)
-            const int uc = tc % NTC;
-            r.x = (real)rel_tile(r.x, s_relc[uc % Shape::TX]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + (uc / Shape::TX) % Shape::TY]);
-            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + uc / (Shape::TX * Shape::TY)]);
+            r.x = (real)rel_tile(r.x, s_relc[tx]); r.y = (real)rel_tile(r.y, s_relc[Shape::TX + ty]);
+            r.z = (real)rel_tile(r.z, s_relc[Shape::TX + Shape::TY + tz]);
         } else if (REL) {
             r.x = (real)(((double)r.x + (double)((sh & 3) - 1) * (double)a.g.len[0]) - org[0]);
             r.y = (real)(((double)r.y + (double)(((sh >> 2) & 3) - 1) * (double)a.g.len[1]) - org[1]);
