@@ -50,8 +50,23 @@ struct RelGrid {
     // of a brick's tile): a tile coordinate is then (round(record x 2^19) + an INTEGER per tile cell) / 2^19, exact in fp32, and
     // two atoms have the same separation in whichever brick's tile they meet -- F_ij = -F_ji to the bit (brick.hpp rel_tile).
     __host__ __device__ __forceinline__ double origin_q(int d, int c) const { return rint((lo[d] + (double)c * cw[d]) * 524288.0); }   // in grid points
+    // c / m and c % m for 0 <= c < 2^24 (a box of 10^8 atoms has 5.6e6 cells): one fp32 multiply and a correction by one instead of
+    // the ~35 instructions of an integer division by a run-time divisor -- twice per atom in every pass that reads relative records
+    __device__ static __forceinline__ int divmod(int c, int m, int &rem) {
+        int q = (int)((float)c * __builtin_amdgcn_rcpf((float)m));       // (v_rcp_f32: 1 ulp, the correction below absorbs it)
+        rem = c - q * m;
+        while (rem < 0) { q--; rem += m; }                   // (the estimate is off by at most one: c < 2^24, two roundings of 6e-8)
+        while (rem >= m) { q++; rem -= m; }
+        return q;
+    }
     __device__ __forceinline__ void origin(int c, double &ox, double &oy, double &oz) const {
-        const int cx = c % M[0], cy = (c / M[0]) % M[1], cz = c / (M[0] * M[1]);
+        int cx, cy, cz;
+        if (c < (1 << 24)) {
+            const int t = divmod(c, M[0], cx);
+            cz = divmod(t, M[1], cy);
+        } else {
+            cx = c % M[0]; cy = (c / M[0]) % M[1]; cz = c / (M[0] * M[1]);
+        }
         ox = origin_q(0, cx) * (1.0 / 524288.0); oy = origin_q(1, cy) * (1.0 / 524288.0); oz = origin_q(2, cz) * (1.0 / 524288.0);
     }
 };
