@@ -3,4 +3,5 @@
 O=gpurun_out/r05p; mkdir -p $O
 timeout -k 10 1150 python -m pytest tests -m gpu -q --timeout 600 --durations=15 > $O/pytest.log 2>&1; rc=$?
 tail -25 $O/pytest.log
-exit $rc
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
