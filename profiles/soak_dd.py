@@ -2,7 +2,7 @@
 that grid by the replica rehearsal (mirror), for thousands of steps while the lattice melts -- populations, ghost counts and migrant
 counts drift, capacities are outgrown and re-learnt.  Printed per window: energy drift, rebuilds, how many ran in the engines' own
 order, how many were redone with exact counts, engines loaded again for room, atoms that changed owner, the rate.
-Usage: python profiles/soak_dd.py [cells=136] [windows=6] [steps_per_window=500]"""
+Usage: python profiles/soak_dd.py [cells=136] [windows=6] [steps_per_window=500] [world=8]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ dev = torch.device("cuda", 0)
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 136
 windows = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+world = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 model = E.LennardJonesModel(2.5, 2.0)
 # the undivided box from the same start (same lattice block, same raw unit-normal velocities per global id): what the ranks' step divides
 import numpy as np
@@ -28,12 +29,12 @@ for w in range(windows):
     t0 = time.perf_counter(); md.step_(per, 0.005); torch.cuda.synchronize(); t = time.perf_counter() - t0
     ep, ek, _ = md.totals()
     t_undivided.append(1e3 * t / per)
-    print("step %5d  dE/E %.2e  T %.4f  rebuilds %d  %.3f ms/step  (/8 = %.4f)" % (50 + per * (w + 1), (ep + ek) / e0 - 1.0, 2 * ek / (3 * n - 3),
-          md.nbr_stats()["builds"] - b0, t_undivided[-1], t_undivided[-1] / 8), flush=True)
+    print("step %5d  dE/E %.2e  T %.4f  rebuilds %d  %.3f ms/step  (/%d = %.4f)" % (50 + per * (w + 1), (ep + ek) / e0 - 1.0, 2 * ek / (3 * n - 3),
+          md.nbr_stats()["builds"] - b0, t_undivided[-1], world, t_undivided[-1] / world), flush=True)
 md.close(); del md
 torch.cuda.empty_cache()
-for label, kw in (("8 in-process domains", dict(rank=None)), ("one rank of 8, replica rehearsal, lock step", dict(rank=0, mirror=True)), ("one rank of 8, replica rehearsal, in order", dict(rank=0, mirror=True))):
-    dd = E.DomainDecomposition.synthetic(cells, 8, kw.pop("rank"), dev, model, pkg=E, raw_velocities=True, **kw)
+for label, kw in (("%d in-process domains" % world, dict(rank=None)), ("one rank of %d, replica rehearsal, lock step" % world, dict(rank=0, mirror=True)), ("one rank of %d, replica rehearsal, in order" % world, dict(rank=0, mirror=True))):
+    dd = E.DomainDecomposition.synthetic(cells, world, kw.pop("rank"), dev, model, pkg=E, raw_velocities=True, **kw)
     n = dd.counts(0)["n_global"]
     if "in order" in label:
         dd.set_overlap_(False)
@@ -50,6 +51,6 @@ for label, kw in (("8 in-process domains", dict(rank=None)), ("one rank of 8, re
               (50 + per * (w + 1), (ep + ek) / e0 - 1.0, 2 * ek / (3 * n - 3), s1["rebuilds"] - s0["rebuilds"],
                p1["rebuilds_in_engine_order"] - p0["rebuilds_in_engine_order"], r1["count_free"] - r0["count_free"], r1["redone"] - r0["redone"],
                p1["engines_regrown"] - p0["engines_regrown"], s1["migrated"] - s0["migrated"], c["n_owned"], c["n_ghost"], 1e3 * t / per) +
-              ("   undivided / 8 / this = %.3f" % (t_undivided[w] / 8 / (1e3 * t / per)) if "rank" in label else ""), flush=True)
+              ("   undivided / %d / this = %.3f" % (world, t_undivided[w] / world / (1e3 * t / per)) if "rank" in label else ""), flush=True)
     dd.close()
     torch.cuda.empty_cache()
