@@ -274,6 +274,7 @@ struct DdImpl : IDd {
     int64_t n_global = 0;
     int max_batch = DD_MAX_BATCH;
     bool overlap = true;
+    bool hold_interior = std::getenv("EMDEE_DD_HOLD_INTERIOR") == nullptr || std::atoi(std::getenv("EMDEE_DD_HOLD_INTERIOR")) != 0;
     bool two_streams = true;              // EMDEE_DD_STREAMS=1: interior and boundary launches on one stream
     bool no_shortcut = false;             // EMDEE_DD_NO_SHORTCUT=1: a one-domain grid goes through the whole ownership path (profiling)
     bool count_free = true;               // EMDEE_DD_COUNT_FREE=0: every rebuild exchanges its row counts first (round 2)
@@ -1324,6 +1325,15 @@ struct DdImpl : IDd {
                 pd->halo_batch_timed = false;
                 hipLaunchKernelGGL(k_dd_batch_begin, dim3(1), dim3(64), 0, pd->stream(), pd->words.ptr, DD_WORDS, carry);
             }
+            // Waiting for the request (the steps the last interval vouched for are done, single steps follow): these steps run IN
+            // ORDER -- halo first, then one launch over all bricks under everybody's word.  Overlapped, the interior launch starts
+            // under the domain's OWN word only, and when the request comes from a neighbour -- for seven of eight ranks it does --
+            // that launch is void: ~0.1 ms per rebuild of a 1.26 M-atom rank thrown away, against a halo left uncovered for the one
+            // or two steps concerned.  Same states either way (EMDEE_DD_HOLD_INTERIOR=0: overlapped throughout, as rounds 3-4).
+            const bool waiting = hold_interior && overlap && rebuild_every == 0 && last_interval > 0 &&
+                                 last_interval - dom[0]->since_build - 1 <= 0 && (world > 1 || dom.size() > 1);
+            struct OverlapBack { bool &o; bool keep; ~OverlapBack() { o = keep; } } overlap_back{overlap, overlap};
+            if (waiting) { join_halo(); overlap = false; }
             for (int j = 0; j < B; j++) {
                 if (lgv_on) join_halo();   // (the boundary half of the previous step still reads the previous noise)
                 for (auto &pd : dom)
