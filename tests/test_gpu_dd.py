@@ -154,24 +154,31 @@ def test_dd_replica_rehearsal_of_one_rank_matches_the_periodic_brick(emdee, orac
 
 
 @pytest.mark.parametrize("world", [1, 4])
-def test_dd_in_order_exchange_gives_the_same_trajectory(emdee, world):
+def test_dd_in_order_exchange_gives_the_same_trajectory(emdee, world, monkeypatch):
     """emdee_dd_set_overlap(0): pack, exchange, unpack and ONE launch over all bricks in order (for one domain per process
     also without any event) -- the same states as the overlapped form with its interior / boundary launches, switched in
-    the middle of a run and back."""
+    the middle of a run and back.  The overlapped form itself runs the steps that WAIT for a rebuild request in order (round 5:
+    no interior launch is started that a neighbour's request would void); EMDEE_DD_HOLD_INTERIOR=0, overlapped throughout as in
+    rounds 3-4, must give the same states bit for bit as well."""
     E = emdee
     pos, vel, eps, sigma, L = _global_box(E.synthetic, uniform=True)
     N = pos.shape[0]
     atoms = E.lennard_jones_atoms(eps, sigma)
     a, b = _build(E, world, pos, vel, atoms, L), _build(E, world, pos, vel, atoms, L)
+    monkeypatch.setenv("EMDEE_DD_HOLD_INTERIOR", "0")
+    c = _build(E, world, pos, vel, atoms, L)
+    monkeypatch.delenv("EMDEE_DD_HOLD_INTERIOR")
     b.set_overlap_(False)
-    a.step_(11, DT, 0); b.step_(11, DT, 0)
+    a.step_(11, DT, 0); b.step_(11, DT, 0); c.step_(11, DT, 0)
     b.set_overlap_(True); a.set_overlap_(False)
-    a.step_(9, DT, 0); b.step_(9, DT, 0)
+    a.step_(9, DT, 0); b.step_(9, DT, 0); c.step_(9, DT, 0)
     xa, va, fa = _gather(a, world, N)
     xb, vb, fb = _gather(b, world, N)
+    xc, vc, fc = _gather(c, world, N)
     assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(fa, fb)
-    assert a.stats()["rebuilds"] == b.stats()["rebuilds"] >= 2
-    a.close(); b.close()
+    assert np.array_equal(xa, xc) and np.array_equal(va, vc) and np.array_equal(fa, fc)
+    assert a.stats()["rebuilds"] == b.stats()["rebuilds"] == c.stats()["rebuilds"] >= 2
+    a.close(); b.close(); c.close()
 
 
 @pytest.mark.parametrize("world,dtype", [(8, "f64"), (3, "f64"), (4, "f32"), (1, "f64")])
